@@ -1,0 +1,136 @@
+/*
+ * include/twixt_hip.h -- C ABI of libtwixt_hip.so, the MI355X (gfx950) batched
+ * TwixT board engine.
+ *
+ * This is the drop-in boundary for the reference's hot path: each entry point
+ * replaces one piece of the reference's Board / TwixTState interface
+ * (stevens68/TwixT_for_open_spiel, open_spiel/games/twixt/), batched over B
+ * independent boards that live in HBM as packed bit-planes.  Citations:
+ * tb.h = twixtboard.h, tb.cc = twixtboard.cc, tw.h = twixt.h, tw.cc = twixt.cc.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no torch types.  Every function returns TWX_OK
+ *     (0) or a negative TWX_E_* code; twx_last_error() gives the text.
+ *   - all `*_dev` pointers are DEVICE pointers owned by the caller (e.g. the
+ *     storage of a torch tensor, or hipMalloc memory of the C++ adapter).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Calls are asynchronous on that stream; the handle is re-entrant, there is
+ *     no global mutable state (the reference's static BlockerMap, tb.h:150, has
+ *     no counterpart).
+ *   - action ids, players, results are the reference's: action = x*N + y
+ *     (tb.cc:599-605), player 0 = red / 1 = blue (tc.h:52-53),
+ *     result 0 open / 1 red win / 2 blue win / 3 draw (tb.h:48).
+ *
+ * Board state (per board, see DESIGN.md "Data layout"): 8 bit-planes of
+ * W = ceil(N*N/32) dwords, bit index = action id:
+ *   0 red pegs, 1 blue pegs, 2..5 links NNE/ENE/ESE/SSE stored at the west
+ *   endpoint, 6 START-border flag, 7 END-border flag          (tc.h:98-108)
+ * followed by 4 scalar dwords:
+ *   s0 = move_counter | move_one_action << 16                  (tb.h:75-77)
+ *   s1 = result | swapped << 8                                 (tb.h:76,78)
+ *   s2 = episode (number of auto-resets, feeds the policy hash)
+ *   s3 = 0 (reserved)
+ * twx_state_words(N) = 8*W + 4.  twx_export_state / twx_import_state use this
+ * order with one board's words contiguous.
+ */
+#ifndef TWIXT_HIP_H_
+#define TWIXT_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWX_OK 0
+#define TWX_E_ARG (-1)     /* bad argument (NULL, range)                         */
+#define TWX_E_SIZE (-2)    /* board_size out of range [5..24]  (tw.cc:139-144)   */
+#define TWX_E_DEVICE (-3)  /* HIP runtime error                                  */
+#define TWX_E_NOMEM (-4)   /* device allocation failed                           */
+
+#define TWX_MIN_BOARD_SIZE 5   /* tb.h:32 */
+#define TWX_MAX_BOARD_SIZE 24  /* tb.h:33 */
+
+/* status byte written per board by twx_step / twx_step_random */
+#define TWX_ST_RESULT_MASK 0x03 /* result after the step (tb.h:48)               */
+#define TWX_ST_ILLEGAL 0x04     /* "Not a legal action" (tw.h:95-97): untouched  */
+#define TWX_ST_RESET 0x10       /* board was auto-reset before this move         */
+#define TWX_ST_SWAPPED 0x20     /* swapped_ (tb.h:76)                            */
+#define TWX_ST_NOOP 0x40        /* terminal board skipped (random mode, no reset)*/
+
+typedef struct twx_env twx_env; /* opaque: owns the device state of B boards */
+
+/* Board::Board(int,bool) x batch (tb.cc:168-174) + TwixTGame range check
+ * (tw.cc:139-144).  Allocates B boards on HIP device `device`, all in the
+ * initial position.  `first_board_id` is the global id of board 0 (the batch
+ * shard offset on multi-GPU runs; it only feeds the random policy's hash). */
+int twx_create(int board_size, int64_t batch, int device, uint64_t first_board_id, twx_env **out);
+int twx_destroy(twx_env *env);
+
+int twx_board_size(const twx_env *env);
+int64_t twx_batch(const twx_env *env);
+int twx_state_words(int board_size);   /* 8*W + 4, or TWX_E_SIZE */
+int twx_mask_words(int board_size);    /* W,       or TWX_E_SIZE */
+
+/* TwixTGame::NewInitialState for every board / for the listed boards
+ * (tw.h:118-120, tb.cc:209-276).  ids_dev: n int32 board indices. */
+int twx_reset(twx_env *env, void *stream);
+int twx_reset_boards(twx_env *env, const int32_t *ids_dev, int64_t n, void *stream);
+
+/* TwixTState::DoApplyAction for every board (tw.h:93-104 -> tb.cc:457-499):
+ * legality check, swap handling, peg + 8-direction link scan with crossing
+ * test, border-flag propagation, result.  actions_dev[B] int32.  A board whose
+ * action is not in its legal set (or that is terminal) is left untouched and
+ * gets TWX_ST_ILLEGAL.  status_dev[B] may be NULL. */
+int twx_step(twx_env *env, const int32_t *actions_dev, uint8_t *status_dev, void *stream);
+
+/* One random-policy env step per board, fused: LegalActions (tw.h:86-90) ->
+ * uniform pick -> DoApplyAction.  action = k-th legal action (ascending),
+ * k = (hash32(seed, first_board_id + b, episode, move_counter) * count) >> 32
+ * (see DESIGN.md "Policy").  auto_reset != 0: a terminal board is re-initialised
+ * (episode+1) and plays move 0 in the same call, so every call performs exactly
+ * B env steps.  actions_out_dev[B] (int32, -1 for skipped) and status_dev[B]
+ * may be NULL. */
+int twx_step_random(twx_env *env, uint32_t seed, int auto_reset, int32_t *actions_out_dev,
+                    uint8_t *status_dev, void *stream);
+
+/* TwixTState::LegalActions as a mask (tw.h:86-90, tb.h:62-64): mask_dev[B][W],
+ * bit a set <=> action a legal for the player to move; all zero if terminal.
+ * count_dev[B] (int32, may be NULL) = number of legal actions. */
+int twx_legal_mask(const twx_env *env, uint32_t *mask_dev, int32_t *count_dev, void *stream);
+
+/* Board::result / move_counter (tb.h:60-61), TwixTState::CurrentPlayer
+ * (tw.h:38; -4 = kTerminalPlayerId when terminal).  Any pointer may be NULL. */
+int twx_status(const twx_env *env, uint8_t *result_dev, int32_t *move_counter_dev,
+               int8_t *current_player_dev, void *stream);
+
+/* TwixTState::ObservationTensor x batch (tw.cc:76-132): out_dev[B][12][N][N-2]
+ * float32, identical for both observers. */
+int twx_observation(const twx_env *env, float *out_dev, void *stream);
+
+/* TwixTState::Clone (tw.h:80-82): dst board dst_ids[i] := src board
+ * src_ids[i].  dst and src may be the same handle but must have equal N. */
+int twx_copy_boards(twx_env *dst, const int32_t *dst_ids_dev, const twx_env *src,
+                    const int32_t *src_ids_dev, int64_t n, void *stream);
+
+/* Raw state of n boards, board-contiguous (layout in the header comment).
+ * ids_dev == NULL means boards 0..n-1. */
+int twx_export_state(const twx_env *env, const int32_t *ids_dev, int64_t n, uint32_t *out_dev,
+                     void *stream);
+int twx_import_state(twx_env *env, const int32_t *ids_dev, int64_t n, const uint32_t *in_dev,
+                     void *stream);
+
+/* Reference-shaped Cell view (tc.h:98-108) of n boards, for renderers and
+ * parity checks: out_dev[n][N*N][4] bytes, cell index x*N+y:
+ *   [0] colour 0 red / 1 blue / 2 empty / 3 off-board (tb.h:50)
+ *   [1] links_ (8 Compass bits)   [2] blocked_neighbors_ (8 bits)
+ *   [3] border flags: bit0 red START, bit1 red END, bit2 blue START, bit3 blue END */
+int twx_export_cells(const twx_env *env, const int32_t *ids_dev, int64_t n, uint8_t *out_dev,
+                     void *stream);
+
+const char *twx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWIXT_HIP_H_ */

@@ -500,6 +500,42 @@ int64_t orc_rollout(orc_state *s, uint32_t seed, uint32_t board, uint32_t *episo
   return played;
 }
 
+int64_t orc_rollout_batch(int n, uint32_t seed, uint32_t first_board, int nboards, int nsteps,
+                          int auto_reset, int threads, uint32_t *planes_out, uint8_t *cells_out,
+                          int32_t *actions_out, uint8_t *status_out) {
+  int64_t total = 0;
+  const int SW = 8 * ((n * n + 31) / 32) + 4;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel reduction(+ : total)
+#endif
+  {
+    orc_state st;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (int b = 0; b < nboards; b++) {
+      uint32_t ep = 0;
+      orc_init(&st, n);
+      total += orc_rollout(&st, seed, first_board + (uint32_t)b, &ep, nsteps, auto_reset,
+                           actions_out ? actions_out + (size_t)b * nsteps : NULL,
+                           status_out ? status_out + (size_t)b * nsteps : NULL);
+      if (planes_out) {
+        orc_export_planes(&st, planes_out + (size_t)b * SW);
+        planes_out[(size_t)b * SW + SW - 2] = ep;
+      }
+      if (cells_out) orc_export_cells(&st, cells_out + (size_t)b * n * n * 4);
+    }
+  }
+  return total;
+}
+
+void orc_block_entry(int dir, int i, int out[3]) {
+  out[0] = kBlock[dir][i][0];
+  out[1] = kBlock[dir][i][1];
+  out[2] = kBlock[dir][i][2];
+}
+
 int64_t orc_bench(int n, uint32_t seed, int nboards, int nsteps, int threads, uint64_t *digest) {
   int64_t total = 0;
   uint64_t dg = 0;

@@ -111,6 +111,17 @@ uint32_t orc_policy_hash(uint32_t seed, uint32_t board, uint32_t episode, uint32
 int64_t orc_rollout(orc_state *s, uint32_t seed, uint32_t board, uint32_t *episode,
                     int nsteps, int auto_reset, int32_t *actions_out, uint8_t *status_out);
 
+/* `nboards` boards (global ids first_board..) x `nsteps` steps, OpenMP over
+ * boards.  Any output may be NULL: planes_out[nboards][8W+4] (orc_export_planes
+ * with s2 = episode), cells_out[nboards][n*n*4], actions_out / status_out
+ * [nboards][nsteps].  Returns env steps played. */
+int64_t orc_rollout_batch(int n, uint32_t seed, uint32_t first_board, int nboards, int nsteps,
+                          int auto_reset, int threads, uint32_t *planes_out, uint8_t *cells_out,
+                          int32_t *actions_out, uint8_t *status_out);
+
+/* the restated blocker table, for tests/test_geometry.py: out = {dx, dy, dir} */
+void orc_block_entry(int dir, int i, int out[3]);
+
 /* cpu_baseline leg: `nboards` boards x `nsteps` steps on `threads` OpenMP
  * threads; returns total env steps, writes a FNV digest over final results. */
 int64_t orc_bench(int n, uint32_t seed, int nboards, int nsteps, int threads, uint64_t *digest);

@@ -79,6 +79,11 @@ def load():
     lib.orc_bench.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, P(C.c_uint64)]
     lib.orc_bench.restype = C.c_int64
     lib.orc_size_ok.argtypes = [C.c_int]
+    lib.orc_rollout_batch.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      P(C.c_uint32), P(C.c_uint8), P(C.c_int32), P(C.c_uint8)]
+    lib.orc_rollout_batch.restype = C.c_int64
+    lib.orc_block_entry.argtypes = [C.c_int, C.c_int, P(C.c_int)]
+    lib.orc_block_entry.restype = None
     _lib = lib
     return lib
 
@@ -163,3 +168,23 @@ class Board:
                                  int(auto_reset), acts.ctypes.data_as(C.POINTER(C.c_int32)),
                                  st.ctypes.data_as(C.POINTER(C.c_uint8)))
         return acts, st, k
+
+
+def rollout_batch(n, seed, first_board, nboards, nsteps, auto_reset=True, threads=0,
+                  want_planes=True, want_cells=False, want_trace=False):
+    """Oracle rollouts of many boards.  Returns dict(steps, planes, cells, actions, status)."""
+    lib = load()
+    W = (n * n + 31) // 32
+    SW = 8 * W + 4
+    planes = np.zeros((nboards, SW), dtype=np.uint32) if want_planes else None
+    cells = np.zeros((nboards, n * n, 4), dtype=np.uint8) if want_cells else None
+    acts = np.zeros((nboards, nsteps), dtype=np.int32) if want_trace else None
+    st = np.zeros((nboards, nsteps), dtype=np.uint8) if want_trace else None
+
+    def p(a, t):
+        return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+    steps = lib.orc_rollout_batch(n, seed, first_board, nboards, nsteps, int(auto_reset), threads,
+                                  p(planes, C.c_uint32), p(cells, C.c_uint8), p(acts, C.c_int32),
+                                  p(st, C.c_uint8))
+    return dict(steps=steps, planes=planes, cells=cells, actions=acts, status=st)
