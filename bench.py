@@ -32,6 +32,24 @@ def algo_bytes(n):
     return ALGO_BYTES.get(n, 2 * (9 * ((n * n + 7) // 8) + 8) + 8)
 
 
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota."""
+    cores = len(os.sched_getaffinity(0))
+    try:  # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = min(cores, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(n, seed, budget_s=12.0):
     """Times the CPU oracle (the scalar port of the reference's algorithm) on all
     host cores with the same policy and workload shape.  Checker code used as a
@@ -44,7 +62,7 @@ def cpu_baseline(n, seed, budget_s=12.0):
     lib = C.CDLL(lib_path)
     lib.orc_bench.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     lib.orc_bench.restype = C.c_int64
-    cores = len(os.sched_getaffinity(0))
+    cores = int(os.environ.get("TWX_CPU_THREADS", "0")) or host_cores()
     dg = C.c_uint64()
     nsteps = 600
     t0 = time.perf_counter()
@@ -58,6 +76,19 @@ def cpu_baseline(n, seed, budget_s=12.0):
     return {"value": s / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": "%d boards x %d random-policy steps (auto-reset), N=%d, %d OpenMP threads, %.1f s"
                       % (nboards, nsteps, n, cores, dt)}
+
+
+def shard_first_board(rank, batch_per_gpu):
+    """Rank r owns the contiguous global board ids [r*B, (r+1)*B)."""
+    return rank * batch_per_gpu
+
+
+def max_over_ranks(value, dist, device):
+    """Whole-job time = the slowest rank's time."""
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def main():
@@ -88,7 +119,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
 
     n, B = args.board_size, args.batch
-    env = TwixtBatchEnv(n, B, local, first_board_id=rank * B)  # contiguous shard of global ids
+    env = TwixtBatchEnv(n, B, local, first_board_id=shard_first_board(rank, B))
 
     def sync_all():
         if world > 1:
@@ -108,9 +139,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, dist, "cuda")
 
     res, mc, _ = env.status()
     hist = torch.bincount(res.to(torch.int64), minlength=4).tolist()

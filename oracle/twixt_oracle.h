@@ -15,7 +15,8 @@
  *     printed states: strings, tensors, legal actions, terminal returns),
  *   - the known answers in twixt_test.cc:108-199 (swap, legal counts, draw),
  *   - the 20-game KAT table of SURVEY.md section 8(c), which was produced from
- *     the compiled reference (LCG policy + FNV-1a digests, fully specified).
+ *     the compiled reference (LCG policy; the moves / result / swapped / links
+ *     columns are matched; its hex digests could not be reproduced).
  * See tests/test_oracle_*.py.
  *
  * Every function cites the reference lines it follows ("tb.cc" =
