@@ -253,3 +253,25 @@ def test_full_size_sample(torch_mod):
     assert torch.equal(popc(red) + popc(blue), counter - swapped)
     assert int(counter.max()) <= n * n - 3
     env.close()
+
+
+@pytest.mark.parametrize("period,pingpong", [(1, 0), (2, 1), (3, 0), (5, 1), (8, 0), (8, 1)])
+def test_journal_periods(torch_mod, period, pingpong, monkeypatch):
+    """The log-structured state must be invisible: any compaction period and block
+    order gives the same trajectories, also when queries (which materialise the
+    journal) are interleaved at odd places."""
+    import oracle_binding as ob
+    monkeypatch.setenv("TWX_JOURNAL_PERIOD", str(period))
+    monkeypatch.setenv("TWX_PINGPONG", str(pingpong))
+    n, batch, seed = 8, 640, 21
+    env = make_env(n, batch, first=9)
+    done = 0
+    for upto in (1, 2, 9, 10, 17, 30, 31, 64, 100, 163):
+        for _ in range(upto - done):
+            env.step_random(seed, True, want_actions=False, want_status=False)
+        done = upto
+        ref = ob.rollout_batch(n, seed, 9, batch, upto, True, want_cells=True)
+        compare_planes(env, ref["planes"], what="period %d after %d steps" % (period, upto))
+        if upto in (9, 31):
+            assert np.array_equal(env.export_cells().cpu().numpy(), ref["cells"])
+    env.close()

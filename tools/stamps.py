@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of step_kernel<24> from the -DTWX_STAMPS build
+(tools/bin/libtwixt_hip_stamps.so).  Never used by the product or the bench."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import twixt_for_open_spiel_amd._lib as L
+L.LIB_PATH = os.path.join(ROOT, "tools", "bin", "libtwixt_hip_stamps.so")
+from twixt_for_open_spiel_amd import TwixtBatchEnv
+
+n, B = 24, 1 << 20
+env = TwixtBatchEnv(n, B)
+for _ in range(704):
+    env.step_random(1, True, want_actions=False, want_status=False)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 16)()
+env.lib.twx_debug_stamps(buf, 1)
+K = 64
+for _ in range(K):
+    env.step_random(1, True, want_actions=False, want_status=False)
+torch.cuda.synchronize()
+env.lib.twx_debug_stamps(buf, 0)
+names = ["loop/prev-store issue", "LDS fill + prefetch issue", "reset/replay", "legal mask", "select",
+         "apply", "flood", "wait prefetch", "status store + loop end", "fixed stores", "dirty chunk stores",
+         "reset lanes / compaction stores"]
+tot = sum(buf[i] for i in range(12))
+wavesteps = K * (B // 64)
+for i, nm in enumerate(names):
+    print("%-28s %9.1f cycles/wave-step  %5.1f %%" % (nm, buf[i] / wavesteps, 100.0 * buf[i] / tot))
+print("total %.1f cycles/wave-step" % (tot / wavesteps))

@@ -21,6 +21,7 @@
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -45,34 +46,50 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 constexpr int kWave = 64;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte vector: stays in VGPRs
 
 // ---------------------------------------------------------------------------
-// LDS addressing: wave region of CH chunks; chunk c of lane l at dword
-// c*256 + l*4 (+0..3).  Word w of a board lives in chunk w>>2, slot w&3.
-// A per-lane word index therefore always maps lane l to banks 4l..4l+3 (mod 32).
+// Internal layout (HBM and LDS alike).  A board is CHT = 2W+3 chunks of 16 B:
+//   chunk 2i   = { red_i, blue_i, linkNNE_i, linkENE_i }      i = 0..W-1
+//   chunk 2i+1 = { linkESE_i, linkSSE_i, start_i, end_i }
+//   chunk 2W   = scalars { s0, s1, s2, s3 }
+//   chunk 2W+1, 2W+2 = redo journal, 8 x 32-bit records
+// i.e. the 8 planes are interleaved word by word: everything about the 32 cells
+// 32i..32i+31 sits in two adjacent chunks.  One address computation per cell /
+// column then reaches every plane through immediate offsets.
+// HBM: state[chunk][board] (uint4); LDS image of a wave: [chunk][lane] (uint4),
+// so chunk c of lane l starts at dword c*256 + l*4.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int lds_idx(int w, int lane) {
-  return ((w >> 2) << 8) + (lane << 2) + (w & 3);
+__device__ __host__ constexpr int plane_off(int p) { return (p >> 2) * 256 + (p & 3); }
+
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {
+  __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_or_b32
+}
+__device__ __forceinline__ void lds_and(uint32_t *p, uint32_t v) {
+  __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_and_b32
+}
+
+// A workgroup is ONE wavefront and the LDS unit executes a wave's DS instructions in
+// issue order, so cross-lane hand-offs through LDS need no s_barrier: only the compiler
+// must not reorder the accesses.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// DPP wavefront shifts: lane i takes the value of lane i-1 / i+1, the end lane gets 0
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
 __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int sh) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
 }
 
-// N-bit column `c` (bits c*N .. c*N+N-1) of the plane starting at word `base`
-// of the board held by `lane`; 0 when c is off the board.
-template <int N>
-__device__ __forceinline__ uint32_t lds_column(const uint32_t *lds, int lane, int base, int c) {
-  const bool ok = (unsigned)c < (unsigned)N;
-  const int o = (ok ? c : 0) * N;
-  const int w0 = base + (o >> 5);
-  const uint32_t lo = lds[lds_idx(w0, lane)];
-  const uint32_t hi = lds[lds_idx(w0 + 1, lane)];  // at worst the first scalar word: in bounds
-  const uint32_t v = funnel(lo, hi, o & 31) & ((1u << N) - 1u);
-  return ok ? v : 0u;
-}
-
-// position of the k-th (0-based) set bit of a non-zero-enough word
+// position of the k-th (0-based) set bit of a word that has more than k bits set
 __device__ __forceinline__ int select_bit(uint32_t t, int k) {
   int pos = 0;
   int c = __popc(t & 0xffffu);
@@ -88,241 +105,425 @@ __device__ __forceinline__ int select_bit(uint32_t t, int k) {
   return pos;
 }
 
-constexpr int kFlagRandom = 1, kFlagAutoReset = 2;
+// In-kernel phase stamps (diagnostic build -DTWX_STAMPS only; never in the shipped
+// library): cycles per phase summed over all waves, read with twx_debug_stamps().
+#ifdef TWX_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {0}
+#define STAMP(i)                                                     \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+    const unsigned long long st_now = __builtin_amdgcn_s_memtime();  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+    st_acc[i] += st_now - st_prev;                                   \
+    st_prev = st_now;                                                \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#define STAMP_FLUSH                                                                      \
+  do {                                                                                   \
+    if (threadIdx.x == 0)                                                                \
+      for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stamps[i_], st_acc[i_]);              \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
 
+constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush = 8, kFlagReverse = 16;
+
+// One launch = one env step on every board (or, with kFlagFlush, just the
+// materialisation of the redo journal).
+//
+// Log-structured state: between two compactions a launch does not
+// rewrite the planes; it appends one 32-bit record of the move to the board's
+// journal (slot `jpos`, the same for every board) and writes back only the
+// scalars chunk and that journal chunk.  The next launches replay slots
+// 0..jpos-1 on top of the planes they stream in.  Every `period`-th launch
+// (kFlagCompact) writes everything and clears the journal.  Lanes that
+// auto-reset write their whole board; lanes whose flood fill changed flag
+// words write those chunks.
 template <int N>
-__global__ __launch_bounds__(kWave) void step_kernel(uint4 *__restrict__ state, long bpad, long batch,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel(uint4 *__restrict__ state, long bpad, long batch,
                                                      const int32_t *__restrict__ actions,
                                                      int32_t *__restrict__ actions_out,
                                                      uint8_t *__restrict__ status, uint32_t seed,
-                                                     uint32_t first_id, int flags) {
+                                                     uint32_t first_id, int flags, int jpos) {
   using G = twx::Geo<N>;
-  constexpr int W = G::W, CH = G::CH, SW = G::SW;
-  constexpr int PR = twx::kPlaneRed * W, PB = twx::kPlaneBlue * W, PL = twx::kPlaneLink0 * W,
-                PS = twx::kPlaneStart * W, PE = twx::kPlaneEnd * W, SC = twx::kNumPlanes * W;
+  constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
+  constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
+                oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
+  constexpr uint32_t kColMask = (1u << N) - 1u;
+  static_assert(CHT == 2 * W + 3 && W <= 32, "layout");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
 
   const int lane = threadIdx.x;
-  const long board = (long)blockIdx.x * kWave + lane;
-  const bool inb = board < batch;
-
-  // ---- stream the 64 boards in (allocation is padded to a multiple of 64) ----
-#pragma unroll
-  for (int c = 0; c < CH; c++) lds4[c * kWave + lane] = state[(long)c * bpad + board];
-  __syncthreads();
-
-  auto L = [&](int w) -> uint32_t & { return lds[lds_idx(w, lane)]; };
-
-  uint32_t counter = L(SC) & 0xffffu, move_one = L(SC) >> 16;
-  uint32_t result = L(SC + 1) & 0xffu, swapped = (L(SC + 1) >> 8) & 1u;
-  uint32_t episode = L(SC + 2);
+  const bool compact = (flags & kFlagCompact) != 0;
+  const bool flush = (flags & kFlagFlush) != 0;
   const bool random = (flags & kFlagRandom) != 0;
+  const long nbatch = bpad / kWave;  // allocation is padded to a multiple of 64 boards
+
+  // Persistent wave: walks batches idx = blockIdx.x, +gridDim.x, ...  While batch k is
+  // processed out of LDS, batch k+1 is already streaming into VGPRs (CHT x 16 B per
+  // lane), so HBM latency hides behind the integer work even at one wave per SIMD.
+  // kFlagReverse walks the batches backwards: the boards a launch touched last are the
+  // ones the next launch touches first (Infinity Cache reuse).
+  auto batch_board = [&](long idx) -> long {
+    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * kWave + lane;
+  };
+  STAMP_DECL;
+  u32x4 nxt[CHT];
+  const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
+  u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
+  long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
+  {
+    const long b0 = batch_board(idx);
+#pragma unroll
+    for (int c = 0; c < CHT; c++) nxt[c] = gstate[(long)c * bpad + b0];
+#pragma unroll
+    for (int c = 0; c < CHT; c++) asm volatile("" ::"v"(nxt[c]));  // first batch: nothing to overlap with
+  }
+  for (; idx < nbatch; idx += gridDim.x) {
+  STAMP(0);  // loop overhead / previous stores issue
+  const long board = batch_board(idx);
+  const bool inb = board < batch;
+  const int a_ext = (!random && !flush && inb) ? actions[board] : -1;
+#pragma unroll
+  for (int c = 0; c < CHT; c++) ldsv[c * kWave + lane] = nxt[c];
+  wave_sync();
+  // prefetch of the next batch, issued in three slices between the phases below so
+  // that the wave never sits behind a 39-deep burst in its memory-issue queue (the
+  // last iteration harmlessly re-reads its own batch)
+  const long b1 = batch_board((idx + gridDim.x < nbatch) ? idx + gridDim.x : idx);
+  auto prefetch = [&](int c0, int c1) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = c0; c < c1; c++) nxt[c] = gstate[(long)c * bpad + b1];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr int kPf1 = CHT / 3, kPf2 = 2 * CHT / 3;
+  prefetch(0, kPf1);
+
+  STAMP(1);  // LDS fill + prefetch issue
+  uint32_t *const me = lds + (lane << 2);  // this lane's slot inside every chunk row
+  // word group i (cells 32i..32i+31) of this lane: me + (i << 9) [+ plane_off(p)]
+  uint32_t *const sc = me + CS * 256;      // scalars
+  uint32_t *const jn = me + CJ * 256;      // journal slot s at jn[(s >> 2) * 256 + (s & 3)]
+
+  const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
+  uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
+  uint32_t result = sv.y & 0xffu, swapped = (sv.y >> 8) & 1u;
+  uint32_t episode = sv.z;
   bool was_reset = false;
 
-  // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in place ----
   if (random && (flags & kFlagAutoReset) && result != 0u && inb) {
+    // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in place ----
 #pragma unroll
-    for (int w = 0; w < SC; w++) L(w) = G::tab.init[w];
+    for (int i = 0; i < W; i++) {
+      *reinterpret_cast<uint4 *>(me + (i << 9)) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4 *>(me + (i << 9) + 256) =
+          make_uint4(0u, 0u, G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
+    }
+    *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(jn + 256) = make_uint4(0u, 0u, 0u, 0u);
     counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
     was_reset = true;
+  } else {
+    // ---- replay the redo journal: slots 0..jpos-1 in order, branch-free ORs ----
+#pragma unroll
+    for (int s = 0; s < twx::kJournalSlots - 1; s++) {
+      if (s < jpos) {  // wave-uniform
+        const uint32_t e = jn[(s >> 2) * 256 + (s & 3)];
+        const int cell = (int)(e & 1023u);
+        const uint32_t bit = (e & twx::kJValid) ? (1u << (cell & 31)) : 0u;  // empty record: every OR is a no-op
+        uint32_t *const g = me + ((cell >> 5) << 9);
+        if (e & (1u << 21)) lds_and(me + ((move_one >> 5) << 9) + oR, ~(1u << (move_one & 31)));  // swap: tb.cc:450-455
+        lds_or(g + oR + ((e >> 10) & 1u), bit);  // peg: red / blue words are adjacent
+#pragma unroll
+        for (int d = 0; d < 4; d++)  // links whose west end is this peg
+          lds_or(g + oL0 + plane_off(twx::kPlaneLink0 + d) - oL0, (e & (1u << (11 + d))) ? bit : 0u);
+#pragma unroll
+        for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
+          const bool on = (e & (1u << (11 + d))) != 0u;
+          const int tc = on ? cell + twx::kDX[d] * N + twx::kDY[d] : cell;
+          lds_or(me + ((tc >> 5) << 9) + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
+        }
+        lds_or(g + oS, (e & (1u << 19)) ? bit : 0u);
+        lds_or(g + oE, (e & (1u << 20)) ? bit : 0u);
+      }
+    }
   }
+  wave_sync();
 
+  STAMP(2);  // reset / journal replay
+  prefetch(kPf1, kPf2);
   const int player = (int)(counter & 1u);
   const bool open = (result == 0u);
 
   // ---- legal mask of the player to move (tw.h:86-90) and the
   //      opponent's free-cell count (for the draw test of tb.cc:202-206) ----
   uint32_t m[W];
-  int cnt = 0, cnt_opp = 0;
+  int cnt_r = 0, cnt_b = 0;
 #pragma unroll
   for (int i = 0; i < W; i++) {
-    const uint32_t r = L(PR + i), b = L(PB + i);
-    const uint32_t reg_cur = player ? G::tab.region[1][i] : G::tab.region[0][i];
-    const uint32_t reg_opp = player ? G::tab.region[0][i] : G::tab.region[1][i];
-    const uint32_t occ = b | (counter == 1u ? 0u : r);  // red's first peg stays legal for blue: the swap
-    m[i] = reg_cur & ~occ;
-    cnt += __popc(m[i]);
-    cnt_opp += __popc(reg_opp & ~(r | b));
+    const uint2 rb = *reinterpret_cast<const uint2 *>(me + (i << 9));
+    const uint32_t occ = rb.x | rb.y;
+    uint32_t mr = G::tab.region[0][i] & ~occ;
+    uint32_t mb = G::tab.region[1][i] & ~occ;
+    cnt_r += __popc(mr);
+    cnt_b += __popc(mb);
+    if (counter == 1u) mb = G::tab.region[1][i] & ~rb.y;  // red's first peg stays legal for blue: the swap
+    m[i] = player ? mb : mr;
   }
+  const int cnt_opp = player ? cnt_r : cnt_b;
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) cnt += __popc(m[i]);
 
+  STAMP(3);  // legal mask + counts
   // ---- choose / validate the action ----
   int a = -1;
-  bool act = inb && open;
+  bool act = inb && open && !flush;
   bool illegal = false;
   if (random) {
     act = act && cnt > 0;
     const uint32_t h = twx::policy_hash(seed, first_id + (uint32_t)board, episode, counter);
-    int k = (int)__umulhi(h, (uint32_t)cnt);
-    int cum = 0, wsel = 0, krem = 0;
+    const int k = (int)__umulhi(h, (uint32_t)cnt);
+    int cum = 0, wsel = 0, base = 0;
     uint32_t msel = m[0];
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-      const int c = __popc(m[i]);
-      if (k >= cum && k < cum + c) { wsel = i; msel = m[i]; krem = k - cum; }
-      cum += c;
+    for (int i = 0; i < W; i++) {  // last word whose prefix count is <= k
+      const bool ge = k >= cum;
+      wsel = ge ? i : wsel;
+      msel = ge ? m[i] : msel;
+      base = ge ? cum : base;
+      cum += __popc(m[i]);
     }
-    a = wsel * 32 + select_bit(msel, krem);
+    a = wsel * 32 + select_bit(msel, k - base);
     if (!act) a = -1;
-  } else {
-    a = inb ? actions[board] : -1;
+  } else if (!flush) {
+    a = a_ext;
     bool legal = false;
     if (a >= 0 && a < N * N) {
       const int ax = a / N, ay = a - ax * N;
       const bool inreg = player ? (ay >= 1 && ay <= N - 2) : (ax >= 1 && ax <= N - 2);
       const uint32_t bit = 1u << (a & 31);
-      const uint32_t r = L(PR + (a >> 5)) & bit, b = L(PB + (a >> 5)) & bit;
-      const bool occ = (b != 0u) || (counter != 1u && r != 0u);
+      const uint2 rb = *reinterpret_cast<const uint2 *>(me + ((a >> 5) << 9));
+      const bool occ = ((rb.y & bit) != 0u) || (counter != 1u && (rb.x & bit) != 0u);
       legal = inreg && !occ;
     }
     illegal = inb && !(open && legal);  // tw.h:95-97 (terminal: LegalActions() is empty)
     act = act && legal;
   }
 
-  int pa = 0;         // cell the peg finally lands on
-  uint32_t pend = 0;  // bit0: flood START from pa, bit1: flood END from pa
+  STAMP(4);  // action select
+  prefetch(kPf2, CHT);
+  int pa = 0;          // cell the peg finally lands on
+  uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
+  uint32_t entry = 0;  // journal record of this move
   if (act) {
     // ---- Board::ApplyAction (tb.cc:457-499) ----
     pa = a;
     const bool swapnow = (counter == 1u) && ((uint32_t)a == move_one);
     if (swapnow) {  // tb.cc:462-473: undo red's first peg, rotate 90 degrees
       swapped = 1u;
-      L(PR + (a >> 5)) &= ~(1u << (a & 31));
+      lds_and(me + ((a >> 5) << 9) + oR, ~(1u << (a & 31)));
       const int ax = a / N, ay = a - ax * N;
       pa = ay * N + (N - 1 - ax);
     }
     const int x = pa / N, y = pa - x * N;
-    const int own = player ? PB : PR;
-    L(own + (pa >> 5)) |= 1u << (pa & 31);  // tb.cc:507-508 set peg
+    lds_or(me + ((pa >> 5) << 9) + oR + player, 1u << (pa & 31));  // tb.cc:507-508 set peg
 
-    // ---- SetPegAndLinks (tb.cc:501-571), all 8 directions at once ----
-    // 5x5 windows (columns x-2..x+2, rows y-2..y+2) of own pegs / START / END
-    uint32_t wo[5], ws[5], we[5];
+    // ---- SetPegAndLinks (tb.cc:501-571), all 8 directions at once.  Six board
+    //      columns x-3..x+2; per column one address, every plane by immediate
+    //      offset.  wo/ws/we: rows y-2..y+2 of own pegs / START / END (columns
+    //      x-2..x+2); win: rows y-3..y+3 of the 4 link planes (columns x-3..x+1) ----
+    uint32_t wo[5], ws[5], we[5], win[twx::kWinCols];
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-      wo[i] = ((lds_column<N>(lds, lane, own, x + i - 2) << 2) >> y) & 0x1fu;
-      ws[i] = ((lds_column<N>(lds, lane, PS, x + i - 2) << 2) >> y) & 0x1fu;
-      we[i] = ((lds_column<N>(lds, lane, PE, x + i - 2) << 2) >> y) & 0x1fu;
+    for (int ci = -3; ci <= 2; ci++) {
+      const int c = x + ci;
+      const bool ok = (unsigned)c < (unsigned)N;
+      const int o = (ok ? c : 0) * N, sh = o & 31;
+      const uint32_t *const g = me + ((o >> 5) << 9);  // next word group: +512 dwords (in bounds: scalars/journal follow)
+      auto col = [&](int off) -> uint32_t {
+        const uint32_t v = funnel(g[off], g[off + 512], sh) & kColMask;
+        return ok ? v : 0u;
+      };
+      if (ci >= -2) {
+        wo[ci + 2] = ((col(oR + player) << 2) >> y) & 0x1fu;
+        ws[ci + 2] = ((col(oS) << 2) >> y) & 0x1fu;
+        we[ci + 2] = ((col(oE) << 2) >> y) & 0x1fu;
+      }
+      if (ci <= 1) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v |= (((col(plane_off(twx::kPlaneLink0 + e)) << 3) >> y) & 0x7fu) << (8 * e);
+        win[ci + 3] = v;
+      }
     }
-    uint32_t cand = 0, ts = 0, te = 0;
+    uint32_t cand = 0, ts = 0, te = 0, blocked = 0;
 #pragma unroll
     for (int d = 0; d < 8; d++) {
       const int ci = twx::kDX[d] + 2, rb = twx::kDY[d] + 2;
       cand |= ((wo[ci] >> rb) & 1u) << d;  // same-colour peg a knight's move away (tb.cc:517)
       ts |= ((ws[ci] >> rb) & 1u) << d;
       te |= ((we[ci] >> rb) & 1u) << d;
-    }
-    uint32_t blocked = 0;
-    if (cand) {
-      // crossing test (tb.cc:519-527): 5 columns x 7 rows x 4 link planes, then
-      // constant masks (twixt_geom.h)
-      uint32_t win[twx::kWinCols];
+      uint32_t hit = 0;  // crossing test (tb.cc:519-527) as constant masks (twixt_geom.h)
 #pragma unroll
-      for (int i = 0; i < twx::kWinCols; i++) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const uint32_t col = lds_column<N>(lds, lane, PL + e * W, x + i - 3);
-          v |= (((col << 3) >> y) & 0x7fu) << (8 * e);
-        }
-        win[i] = v;
-      }
-#pragma unroll
-      for (int d = 0; d < 8; d++) {
-        uint32_t hit = 0;
-#pragma unroll
-        for (int i = 0; i < twx::kWinCols; i++) hit |= win[i] & twx::kCross.m[d][i];
-        blocked |= (hit != 0u ? 1u : 0u) << d;
-      }
+      for (int i = 0; i < twx::kWinCols; i++) hit |= win[i] & twx::kCross.m[d][i];
+      blocked |= (hit != 0u ? 1u : 0u) << d;
     }
     const uint32_t linkm = cand & ~blocked;
+    {  // tb.cc:532-533: one stored bit per physical link, at its west end
+      uint32_t *const g = me + ((pa >> 5) << 9);
+      const uint32_t bit = 1u << (pa & 31);
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-      if (linkm & (1u << d)) {  // tb.cc:532-533: one stored bit per physical link, at the west end
-        const int cell = (d < 4) ? pa : pa + twx::kDX[d] * N + twx::kDY[d];
-        L(PL + (d & 3) * W + (cell >> 5)) |= 1u << (cell & 31);
+      for (int d = 0; d < 4; d++) lds_or(g + plane_off(twx::kPlaneLink0 + d), (linkm & (1u << d)) ? bit : 0u);
+#pragma unroll
+      for (int d = 4; d < 8; d++) {
+        const bool on = (linkm & (1u << d)) != 0u;
+        const int tc = on ? pa + twx::kDX[d] * N + twx::kDY[d] : pa;
+        lds_or(me + ((tc >> 5) << 9) + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
+      }
+      // tb.cc:538-546: inherit START, else END, else remember a neutral neighbour
+      const uint32_t gain_s = linkm & ts, gain_e = linkm & ~ts & te, neutral = linkm & ~ts & ~te;
+      const bool p_s = ((ws[2] >> 2) & 1u) || gain_s;
+      const bool p_e = ((we[2] >> 2) & 1u) || gain_e;
+      lds_or(g + oS, gain_s ? bit : 0u);
+      lds_or(g + oE, gain_e ? bit : 0u);
+      if (linkm && neutral) pend = (p_s ? 1u : 0u) | (p_e ? 2u : 0u);  // tb.cc:558-570
+      entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
+              (gain_s ? 1u << 19 : 0u) | (gain_e ? 1u << 20 : 0u) | (swapnow ? 1u << 21 : 0u);
+
+      if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
+      counter += 1u;
+      // ---- UpdateResult (tb.cc:192-207) ----
+      if (p_s && p_e) {
+        result = player ? 2u : 1u;
+      } else if (counter > 2u) {
+        const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
+        if (cnt_opp - (in_opp ? 1 : 0) == 0) result = 3u;
       }
     }
-    // tb.cc:538-546: inherit START, else END, else remember a neutral neighbour
-    const uint32_t gain_s = linkm & ts, gain_e = linkm & ~ts & te, neutral = linkm & ~ts & ~te;
-    const bool p_s = ((ws[2] >> 2) & 1u) || gain_s;
-    const bool p_e = ((we[2] >> 2) & 1u) || gain_e;
-    if (gain_s) L(PS + (pa >> 5)) |= 1u << (pa & 31);
-    if (gain_e) L(PE + (pa >> 5)) |= 1u << (pa & 31);
-    if (linkm && neutral) pend = (p_s ? 1u : 0u) | (p_e ? 2u : 0u);  // tb.cc:558-570
-
-    if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
-    counter += 1u;
-    // ---- UpdateResult (tb.cc:192-207) ----
-    if (p_s && p_e) {
-      result = player ? 2u : 1u;
-    } else if (counter > 2u) {
-      const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
-      if (cnt_opp - (in_opp ? 1 : 0) == 0) result = 3u;
-    }
   }
-  L(SC) = counter | (move_one << 16);
-  L(SC + 1) = result | (swapped << 8);
-  L(SC + 2) = episode;
-  L(SC + 3) = 0u;
-  __syncthreads();
+  STAMP(5);  // apply: windows, crossing test, links, result
+  // s3 is used below as the board's dirty mask (bit i: flag words of group i changed)
+  *reinterpret_cast<uint4 *>(sc) = make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
+  if (compact) {
+    *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(jn + 256) = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    jn[(jpos >> 2) * 256 + (jpos & 3)] = entry;
+  }
+  wave_sync();
 
-  // ---- ExploreLocalGraph (tb.cc:573-588), wave-cooperative: for each board
-  //      that needs it, lane c holds column c; frontier expansion over the four
-  //      link planes until no new cell is reached ----
+  // ---- ExploreLocalGraph (tb.cc:573-588), wave-cooperative, two boards per pass:
+  //      lanes 0..31 work on one board that needs a fill, lanes 32..63 on another;
+  //      lane c (within its half) holds column c of the four link planes and of the
+  //      flag plane.  Frontier expansion: columns move by DPP wave shifts (1 VALU
+  //      op each), rows by bit shifts; stop when no half found a new cell. ----
   uint64_t todo = __ballot(pend != 0u);
   while (todo) {
-    const int src = (int)__ffsll((unsigned long long)todo) - 1;
+    const int s0 = (int)__ffsll((unsigned long long)todo) - 1;
     todo &= todo - 1;
-    const int spa = __builtin_amdgcn_readlane(pa, src);
-    const uint32_t spend = (uint32_t)__builtin_amdgcn_readlane((int)pend, src);
+    const bool two = todo != 0ull;
+    const int s1 = two ? (int)__ffsll((unsigned long long)todo) - 1 : s0;
+    if (two) todo &= todo - 1;
+    const int half = lane >> 5, c = lane & 31;
+    const int src = half ? s1 : s0;
+    const int spa = half ? __builtin_amdgcn_readlane(pa, s1) : __builtin_amdgcn_readlane(pa, s0);
+    const uint32_t spend = (half && !two) ? 0u
+                           : (uint32_t)(half ? __builtin_amdgcn_readlane((int)pend, s1)
+                                             : __builtin_amdgcn_readlane((int)pend, s0));
     const int sx = spa / N, sy = spa - sx * N;
-    const int c = lane;
+    const bool ok = c < N;
+    const int o = (ok ? c : 0) * N, sh = o & 31, grp = o >> 5;
+    uint32_t *const g = lds + (src << 2) + (grp << 9);  // board `src`, this lane's column
+    auto col = [&](int off) -> uint32_t {
+      const uint32_t v = funnel(g[off], g[off + 512], sh) & kColMask;
+      return ok ? v : 0u;
+    };
     uint32_t lk[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) lk[e] = lds_column<N>(lds, src, PL + e * W, c);
+    for (int e = 0; e < 4; e++) lk[e] = col(plane_off(twx::kPlaneLink0 + e));
 #pragma unroll
     for (int f = 0; f < 2; f++) {
-      if (!(spend & (1u << f))) continue;  // wave-uniform
-      const int base = f ? PE : PS;
-      const uint32_t flag0 = lds_column<N>(lds, src, base, c);
+      const bool en = (spend >> f) & 1u;  // uniform per half
+      if (!__ballot(en)) continue;
+      const int off = f ? oE : oS;
+      const uint32_t flag0 = col(off);
       uint32_t flag = flag0;
-      uint32_t front = (c == sx) ? (1u << sy) : 0u;
+      uint32_t front = (en && c == sx) ? (1u << sy) : 0u;
       for (;;) {
-        uint32_t nb = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int dx = twx::kDX[e], dy = twx::kDY[e];
-          // forward: frontier cell with link e reaches (c+dx, y+dy)
-          uint32_t s = __shfl(front & lk[e], c - dx);
-          if (c - dx < 0) s = 0u;
-          nb |= (dy > 0) ? (s << dy) : (s >> (-dy));
-          // backward: cell (c,y) whose link e ends in the frontier
-          uint32_t t = __shfl(front, c + dx);
-          if (c + dx >= N) t = 0u;
-          t = (dy > 0) ? (t >> dy) : (t << (-dy));
-          nb |= t & lk[e];
-        }
-        const uint32_t fresh = (c < N) ? (nb & ~flag & ((1u << N) - 1u)) : 0u;
+        // forward: a frontier cell with link e reaches (c+dx, y+dy).  dx = 1 for NNE/SSE,
+        // 2 for ENE/ESE: merge the row-shifted pairs, then shift lanes right by dx
+        const uint32_t a1 = ((front & lk[0]) << 2) | ((front & lk[3]) >> 2);
+        const uint32_t a2 = ((front & lk[1]) << 1) | ((front & lk[2]) >> 1);
+        uint32_t nb = wave_shr1(a1) | wave_shr1(wave_shr1(a2));
+        // backward: cell (c,y) whose link e ends in the frontier at (c+dx, y+dy)
+        const uint32_t f1 = wave_shl1(front), f2 = wave_shl1(f1);
+        nb |= ((f1 >> 2) & lk[0]) | ((f2 >> 1) & lk[1]) | ((f2 << 1) & lk[2]) | ((f1 << 2) & lk[3]);
+        const uint32_t fresh = ok ? (nb & ~flag & kColMask) : 0u;
         flag |= fresh;
         front = fresh;
         if (__ballot(fresh != 0u) == 0ull) break;
       }
       const uint32_t add = flag & ~flag0;
-      if (c < N && add) {
-        const int o = c * N, w0 = base + (o >> 5), sh = o & 31;
-        atomicOr(&lds[lds_idx(w0, src)], add << sh);
-        if (sh + N > 32) atomicOr(&lds[lds_idx(w0 + 1, src)], add >> (32 - sh));
+      if (ok && add) {
+        uint32_t dirty = 1u << grp;
+        lds_or(g + off, add << sh);
+        if (sh + N > 32) {
+          lds_or(g + off + 512, add >> (32 - sh));
+          dirty |= 2u << grp;
+        }
+        lds_or(lds + (src << 2) + CS * 256 + 3, dirty);
       }
-      __syncthreads();
+      wave_sync();
     }
   }
-  __syncthreads();
+  wave_sync();
+  STAMP(6);  // flood fill
+  const uint32_t dirty = sc[3];
+  sc[3] = 0u;
+  wave_sync();
 
-  // ---- stream the boards back ----
+  // The prefetched batch has had the whole step to arrive: retire its loads HERE, before
+  // this batch's stores are issued, so that the wait at the top of the next iteration
+  // does not also wait for those stores (loads and stores share one in-order counter).
 #pragma unroll
-  for (int c = 0; c < CH; c++) state[(long)c * bpad + board] = lds4[c * kWave + lane];
-  if (inb) {
+  for (int c = 0; c < CHT; c++) asm volatile("" ::"v"(nxt[c]));
+
+  STAMP(7);  // wait for the prefetched batch
+  // ---- stream back ----
+  if (compact) {
+#pragma unroll
+    for (int c = 0; c < CHT; c++) state[(long)c * bpad + board] = lds4[c * kWave + lane];
+  } else {
+    state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
+    const int jc = CJ + (jpos >> 2);                           // the journal chunk of slot jpos
+    state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+    STAMP(9);  // fixed stores (scalars + journal chunk)
+    // flag chunks a flood fill changed: every dirty lane walks its own mask, all dirty
+    // lanes in parallel (per-lane chunk index), so the loop runs max-popcount times
+    uint32_t dd = was_reset ? 0u : dirty;
+    while (__ballot(dd != 0u)) {
+      if (dd) {
+        const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
+        dd &= dd - 1;
+        state[(long)c * bpad + board] = lds4[c * kWave + lane];
+      }
+    }
+    STAMP(10);  // dirty flag chunks
+    if (__ballot(was_reset)) {  // auto-reset lanes rewrite their whole board
+#pragma unroll
+      for (int c = 0; c < CHT; c++)
+        if (was_reset) state[(long)c * bpad + board] = lds4[c * kWave + lane];
+    }
+  }
+  STAMP(11);  // reset lanes / compaction
+  if (inb && !flush) {
     if (status) {
       uint8_t st = (uint8_t)(result | (swapped << 5));
       if (illegal) st |= TWX_ST_ILLEGAL;
@@ -332,7 +533,10 @@ __global__ __launch_bounds__(kWave) void step_kernel(uint4 *__restrict__ state, 
     }
     if (actions_out) actions_out[board] = a;
   }
-  (void)SW;
+  wave_sync();
+  STAMP(8);  // stream back + status
+  }  // batch loop
+  STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------
@@ -340,7 +544,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(uint4 *__restrict__ state, 
 // queries.  One thread per (board, chunk) or per board.
 // ---------------------------------------------------------------------------
 struct Dims {
-  int n, W, SW, CH;
+  int n, W, SW, CH, CHT;  // CH: state chunks (planes + scalars); CHT: + journal chunks
   long batch, bpad;
 };
 
@@ -348,37 +552,42 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v, int j) {
   return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
 }
 
-__device__ __forceinline__ uint32_t state_word(const uint4 *state, const Dims &d, long b, int w) {
-  return comp(state[(long)(w >> 2) * d.bpad + b], w & 3);
+// word i of plane p / scalar j of board b in the interleaved internal layout
+__device__ __forceinline__ uint32_t plane_word(const uint4 *state, const Dims &d, long b, int p, int i) {
+  return comp(state[(long)(2 * i + (p >> 2)) * d.bpad + b], p & 3);
+}
+__device__ __forceinline__ uint32_t scalar_word(const uint4 *state, const Dims &d, long b, int j) {
+  return comp(state[(long)(2 * d.W) * d.bpad + b], j);
 }
 
 __global__ void reset_kernel(uint4 *state, Dims d, const uint32_t *init, const int32_t *ids, long n) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long j = t % (ids ? n : d.bpad);
   const int c = (int)(t / (ids ? n : d.bpad));
-  if (c >= d.CH) return;
+  if (c >= d.CHT) return;
   long b = j;
   if (ids) {
     b = ids[j];
     if (b < 0 || b >= d.batch) return;
   }
-  uint4 v;
+  uint4 v;  // init is in internal chunk order; scalars and journal chunks are zero
   v.x = init[4 * c + 0]; v.y = init[4 * c + 1]; v.z = init[4 * c + 2]; v.w = init[4 * c + 3];
   state[(long)c * d.bpad + b] = v;
 }
 
+// canonical (include/twixt_hip.h) order out: one thread per (board, word)
 __global__ void export_kernel(const uint4 *state, Dims d, const int32_t *ids, long n, uint32_t *out) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long j = t / d.CH;
-  const int c = (int)(t % d.CH);
+  const long j = t / d.SW;
+  const int w = (int)(t % d.SW);
   if (j >= n) return;
   const long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) return;
-  const uint4 v = state[(long)c * d.bpad + b];
-  uint32_t *o = out + j * d.SW + 4 * c;
-  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  const int np = twx::kNumPlanes * d.W;
+  out[j * d.SW + w] = (w < np) ? plane_word(state, d, b, w / d.W, w % d.W) : scalar_word(state, d, b, w - np);
 }
 
+// canonical order in: one thread per (board, chunk 0..2W)
 __global__ void import_kernel(uint4 *state, Dims d, const int32_t *ids, long n, const uint32_t *in) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long j = t / d.CH;
@@ -386,9 +595,16 @@ __global__ void import_kernel(uint4 *state, Dims d, const int32_t *ids, long n, 
   if (j >= n) return;
   const long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) return;
-  const uint32_t *i = in + j * d.SW + 4 * c;
+  const uint32_t *src = in + j * d.SW;
   uint4 v;
-  v.x = i[0]; v.y = i[1]; v.z = i[2]; v.w = i[3];
+  if (c < 2 * d.W) {
+    const int i = c >> 1, p0 = (c & 1) * 4;
+    v.x = src[(p0 + 0) * d.W + i]; v.y = src[(p0 + 1) * d.W + i];
+    v.z = src[(p0 + 2) * d.W + i]; v.w = src[(p0 + 3) * d.W + i];
+  } else {
+    const uint32_t *sc = src + twx::kNumPlanes * d.W;
+    v.x = sc[0]; v.y = sc[1]; v.z = sc[2]; v.w = sc[3];
+  }
   state[(long)c * d.bpad + b] = v;
 }
 
@@ -410,13 +626,12 @@ __global__ void legal_mask_kernel(const uint4 *state, Dims d, const uint32_t *re
   const long b = t % d.batch;
   const int i = (int)(t / d.batch);
   if (i >= d.W) return;
-  const int SC = twx::kNumPlanes * d.W;
-  const uint32_t s0 = state_word(state, d, b, SC), s1 = state_word(state, d, b, SC + 1);
+  const uint32_t s0 = scalar_word(state, d, b, 0), s1 = scalar_word(state, d, b, 1);
   const uint32_t counter = s0 & 0xffffu, result = s1 & 0xffu;
   const int player = (int)(counter & 1u);
   uint32_t mword = 0;
   if (result == 0u) {
-    const uint32_t r = state_word(state, d, b, i), bl = state_word(state, d, b, d.W + i);
+    const uint32_t r = plane_word(state, d, b, twx::kPlaneRed, i), bl = plane_word(state, d, b, twx::kPlaneBlue, i);
     const uint32_t occ = bl | (counter == 1u ? 0u : r);
     mword = region[player * d.W + i] & ~occ;
   }
@@ -439,7 +654,7 @@ __global__ void status_kernel(const uint4 *state, Dims d, uint8_t *result, int32
 }
 
 __device__ __forceinline__ int plane_bit(const uint4 *state, const Dims &d, long b, int plane, int cell) {
-  return (state_word(state, d, b, plane * d.W + (cell >> 5)) >> (cell & 31)) & 1;
+  return (plane_word(state, d, b, plane, cell >> 5) >> (cell & 31)) & 1;
 }
 
 // reference-shaped Cell view (tc.h:98-108): one thread per (board, cell)
@@ -522,15 +737,18 @@ __global__ void observation_kernel(const uint4 *state, Dims d, float *out) {
 
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
-                       uint8_t *status, uint32_t seed, uint32_t first_id, int flags, hipStream_t s) {
-  constexpr size_t lds_bytes = (size_t)twx::Geo<N>::CH * kWave * 16;  // 37 KiB at N=24: 4 waves per CU
-  hipLaunchKernelGGL(step_kernel<N>, dim3((unsigned)(bpad / kWave)), dim3(kWave), lds_bytes, s, state, bpad,
-                     batch, actions, actions_out, status, seed, first_id, flags);
+                       uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
+                       hipStream_t s) {
+  constexpr size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // 39 KiB at N=24: 4 waves per CU
+  const long nbatch = bpad / kWave;
+  const long grid = nbatch < (long)waves ? nbatch : (long)waves;
+  hipLaunchKernelGGL(step_kernel<N>, dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
+                     batch, actions, actions_out, status, seed, first_id, flags, jpos);
   return hipGetLastError();
 }
 
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, hipStream_t);
+                              int, int, int, hipStream_t);
 
 template <int N>
 struct StepTable {
@@ -563,8 +781,57 @@ struct twx_env {
   int device;
   uint64_t first_id;
   uint4 *state;
-  uint32_t *tables;  // region[2][W] then init[SW]
+  uint32_t *tables;  // region[2][W] then the initial board in internal chunk order
+  // log-structured state: launches since the last compaction (= journal slots in
+  // use, identical for every board), compaction period (1..kJournalSlots), and
+  // the launch counter that alternates the block order (Infinity Cache reuse)
+  int jpos, period;
+  bool pingpong;
+  uint64_t launches;
+  int waves;  // persistent grid: resident waves = CUs x waves the LDS image admits per CU
 };
+
+namespace {
+
+int env_int(const char *name, int dflt, int lo, int hi) {
+  const char *v = getenv(name);
+  if (!v || !*v) return dflt;
+  const int x = atoi(v);
+  return x < lo ? lo : x > hi ? hi : x;
+}
+
+// one env step (or a flush) on every board; maintains the journal position
+int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *status, uint32_t seed,
+             int flags, hipStream_t s) {
+  const bool flush = (flags & kFlagFlush) != 0;
+  if (flush || e->jpos == e->period - 1) flags |= kFlagCompact;
+  if (e->pingpong && (e->launches & 1)) flags |= kFlagReverse;
+  HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
+                           (uint32_t)e->first_id, flags, e->jpos, e->waves, s));
+  e->jpos = (flags & kFlagCompact) ? 0 : e->jpos + 1;
+  e->launches++;
+  return TWX_OK;
+}
+
+// every entry point other than the step functions sees materialised planes
+int materialise(const twx_env *ce, hipStream_t s) {
+  twx_env *e = const_cast<twx_env *>(ce);
+  if (e->jpos == 0) return TWX_OK;
+  return run_step(e, nullptr, nullptr, nullptr, 0u, kFlagFlush, s);
+}
+
+}  // namespace
+
+#ifdef TWX_STAMPS
+extern "C" int twx_debug_stamps(unsigned long long *out, int reset) {
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z));
+  }
+  return TWX_OK;
+}
+#endif
 
 extern "C" {
 
@@ -592,19 +859,38 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->d.W = twx::plane_words(n);
   e->d.SW = twx::state_words(n);
   e->d.CH = twx::state_chunks(n);
+  e->d.CHT = twx::total_chunks(n);
+  e->jpos = 0;
+  e->period = env_int("TWX_JOURNAL_PERIOD", twx::kJournalSlots, 1, twx::kJournalSlots);
+  e->pingpong = env_int("TWX_PINGPONG", 1, 0, 1) != 0;
+  e->launches = 0;
+  {
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    const int lds_per_wave = e->d.CHT * kWave * 16;
+    int per_cu = (160 * 1024) / lds_per_wave;  // MI355X: 160 KiB LDS per CU
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    e->waves = (cus > 0 ? cus : 256) * env_int("TWX_WAVES_PER_CU", per_cu, 1, 32);
+  }
   e->d.batch = batch;
   e->d.bpad = (batch + kWave - 1) / kWave * kWave;
   e->device = device;
   e->first_id = first_board_id;
   e->state = nullptr;
   e->tables = nullptr;
-  const size_t bytes = (size_t)e->d.CH * (size_t)e->d.bpad * sizeof(uint4);
+  const size_t bytes = (size_t)e->d.CHT * (size_t)e->d.bpad * sizeof(uint4);
   if (hipMalloc(&e->state, bytes) != hipSuccess) {
     delete e;
     return fail(TWX_E_NOMEM, "twx_create: hipMalloc of " + std::to_string(bytes) + " bytes failed");
   }
-  std::vector<uint32_t> tab(2 * e->d.W + e->d.SW);
-  twx::fill_tables(n, tab.data(), tab.data() + 2 * e->d.W);
+  // tables: region[2][W], then the initial position in internal chunk order (CHT*4 words)
+  std::vector<uint32_t> canon(2 * e->d.W + e->d.SW), tab(2 * e->d.W + 4 * e->d.CHT, 0u);
+  twx::fill_tables(n, canon.data(), canon.data() + 2 * e->d.W);
+  for (int i = 0; i < 2 * e->d.W; i++) tab[i] = canon[i];
+  for (int p = 0; p < twx::kNumPlanes; p++)
+    for (int i = 0; i < e->d.W; i++)
+      tab[2 * e->d.W + 4 * (2 * i + (p >> 2)) + (p & 3)] = canon[2 * e->d.W + p * e->d.W + i];
   if (hipMalloc(&e->tables, tab.size() * 4) != hipSuccess ||
       hipMemcpy(e->tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(e->state);
@@ -633,7 +919,8 @@ int64_t twx_batch(const twx_env *e) { return e ? e->d.batch : TWX_E_ARG; }
 
 int twx_reset(twx_env *e, void *stream) {
   if (!e) return fail(TWX_E_ARG, "twx_reset: env is NULL");
-  const long threads = (long)e->d.CH * e->d.bpad;
+  e->jpos = 0;  // every journal is cleared below
+  const long threads = (long)e->d.CHT * e->d.bpad;
   hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, e->tables + 2 * e->d.W, (const int32_t *)nullptr, 0L);
   HIP_TRY(hipGetLastError());
@@ -643,7 +930,8 @@ int twx_reset(twx_env *e, void *stream) {
 int twx_reset_boards(twx_env *e, const int32_t *ids, int64_t n, void *stream) {
   if (!e || !ids || n < 0) return fail(TWX_E_ARG, "twx_reset_boards: bad argument");
   if (n == 0) return TWX_OK;
-  const long threads = (long)e->d.CH * n;
+  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
+  const long threads = (long)e->d.CHT * n;
   hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, e->tables + 2 * e->d.W, ids, (long)n);
   HIP_TRY(hipGetLastError());
@@ -652,23 +940,20 @@ int twx_reset_boards(twx_env *e, const int32_t *ids, int64_t n, void *stream) {
 
 int twx_step(twx_env *e, const int32_t *actions, uint8_t *status, void *stream) {
   if (!e || !actions) return fail(TWX_E_ARG, "twx_step: env or actions is NULL");
-  HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, nullptr, status, 0u,
-                           (uint32_t)e->first_id, 0, (hipStream_t)stream));
-  return TWX_OK;
+  return run_step(e, actions, nullptr, status, 0u, 0, (hipStream_t)stream);
 }
 
 int twx_step_random(twx_env *e, uint32_t seed, int auto_reset, int32_t *actions_out, uint8_t *status,
                     void *stream) {
   if (!e) return fail(TWX_E_ARG, "twx_step_random: env is NULL");
   const int flags = kFlagRandom | (auto_reset ? kFlagAutoReset : 0);
-  HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, nullptr, actions_out, status, seed,
-                           (uint32_t)e->first_id, flags, (hipStream_t)stream));
-  return TWX_OK;
+  return run_step(e, nullptr, actions_out, status, seed, flags, (hipStream_t)stream);
 }
 
 int twx_legal_mask(const twx_env *e, uint32_t *mask, int32_t *count, void *stream) {
   if (!e || !mask) return fail(TWX_E_ARG, "twx_legal_mask: env or mask is NULL");
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = materialise(e, s)) return rc;
   if (count) HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t) * e->d.batch, s));
   const long threads = (long)e->d.W * e->d.batch;
   hipLaunchKernelGGL(legal_mask_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, e->state, e->d,
@@ -680,6 +965,7 @@ int twx_legal_mask(const twx_env *e, uint32_t *mask, int32_t *count, void *strea
 int twx_status(const twx_env *e, uint8_t *result, int32_t *move_counter, int8_t *current_player,
                void *stream) {
   if (!e) return fail(TWX_E_ARG, "twx_status: env is NULL");
+  // (scalars are written by every launch: no materialisation needed)
   hipLaunchKernelGGL(status_kernel, dim3(blocks_for(e->d.batch, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, result, move_counter, current_player);
   HIP_TRY(hipGetLastError());
@@ -688,6 +974,7 @@ int twx_status(const twx_env *e, uint8_t *result, int32_t *move_counter, int8_t 
 
 int twx_observation(const twx_env *e, float *out, void *stream) {
   if (!e || !out) return fail(TWX_E_ARG, "twx_observation: env or out is NULL");
+  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)12 * e->d.n * (e->d.n - 2) * e->d.batch;
   hipLaunchKernelGGL(observation_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, out);
@@ -700,6 +987,8 @@ int twx_copy_boards(twx_env *dst, const int32_t *dst_ids, const twx_env *src, co
   if (!dst || !src || !dst_ids || !src_ids || n < 0) return fail(TWX_E_ARG, "twx_copy_boards: bad argument");
   if (dst->d.n != src->d.n) return fail(TWX_E_ARG, "twx_copy_boards: board sizes differ");
   if (n == 0) return TWX_OK;
+  if (int rc = materialise(dst, (hipStream_t)stream)) return rc;
+  if (int rc = materialise(src, (hipStream_t)stream)) return rc;
   const long threads = (long)dst->d.CH * n;
   hipLaunchKernelGGL(copy_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      dst->state, dst->d, dst_ids, src->state, src->d, src_ids, (long)n);
@@ -710,7 +999,8 @@ int twx_copy_boards(twx_env *dst, const int32_t *dst_ids, const twx_env *src, co
 int twx_export_state(const twx_env *e, const int32_t *ids, int64_t n, uint32_t *out, void *stream) {
   if (!e || !out || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_export_state: bad argument");
   if (n == 0) return TWX_OK;
-  const long threads = (long)e->d.CH * n;
+  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
+  const long threads = (long)e->d.SW * n;
   hipLaunchKernelGGL(export_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, ids, (long)n, out);
   HIP_TRY(hipGetLastError());
@@ -720,6 +1010,7 @@ int twx_export_state(const twx_env *e, const int32_t *ids, int64_t n, uint32_t *
 int twx_import_state(twx_env *e, const int32_t *ids, int64_t n, const uint32_t *in, void *stream) {
   if (!e || !in || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_import_state: bad argument");
   if (n == 0) return TWX_OK;
+  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)e->d.CH * n;
   hipLaunchKernelGGL(import_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, ids, (long)n, in);
@@ -730,6 +1021,7 @@ int twx_import_state(twx_env *e, const int32_t *ids, int64_t n, const uint32_t *
 int twx_export_cells(const twx_env *e, const int32_t *ids, int64_t n, uint8_t *out, void *stream) {
   if (!e || !out || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_export_cells: bad argument");
   if (n == 0) return TWX_OK;
+  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)e->d.n * e->d.n * n;
   hipLaunchKernelGGL(cells_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, ids, (long)n, out);

@@ -34,6 +34,15 @@ constexpr int plane_words(int n) { return (n * n + 31) / 32; }
 constexpr int state_words(int n) { return kNumPlanes * plane_words(n) + 4; }
 constexpr int state_chunks(int n) { return state_words(n) / 4; }  // 16-byte chunks
 
+// Redo journal (DESIGN.md "Log-structured state"): kJournalSlots 32-bit move
+// records per board, stored in kJournalChunks extra chunks after the state.
+constexpr int kJournalSlots = 8;
+constexpr int kJournalChunks = kJournalSlots / 4;
+constexpr int total_chunks(int n) { return state_chunks(n) + kJournalChunks; }
+// record: bit31 valid | cell[9:0] | player[10] | link mask[18:11] | gain START[19] |
+//         gain END[20] | swap[21]
+constexpr uint32_t kJValid = 0x80000000u;
+
 constexpr bool is_corner(int n, int x, int y) {
   return (x == 0 || x == n - 1) && (y == 0 || y == n - 1);
 }
@@ -94,7 +103,8 @@ template <int N>
 struct Geo {
   static constexpr int W = plane_words(N);
   static constexpr int SW = state_words(N);
-  static constexpr int CH = state_chunks(N);
+  static constexpr int CH = state_chunks(N);   // planes + scalars
+  static constexpr int CHT = total_chunks(N);  // + journal
   struct Tab {
     uint32_t region[2][W];
     uint32_t init[SW];  // the initial position (tb.cc:209-236)
