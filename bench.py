@@ -78,6 +78,21 @@ def cpu_baseline(n, seed, budget_s=12.0):
                       % (nboards, nsteps, n, cores, dt)}
 
 
+def measured_traffic(n, batch):
+    """HBM bytes per launch of step_kernel<N> from the committed rocprofv3 PMC passes
+    (profiles/traffic_step_kernel_n24.json: FETCH_SIZE x2 per the gfx950 correction +
+    WRITE_SIZE).  Counters cannot be collected inside this process; None if the
+    committed measurement does not cover this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_step_kernel_n24.json")
+    if n != 24 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_env_step"]) * batch
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def shard_first_board(rank, batch_per_gpu):
     """Rank r owns the contiguous global board ids [r*B, (r+1)*B)."""
     return rank * batch_per_gpu
@@ -168,9 +183,13 @@ def main():
                        "prologue_steps": args.prologue, "sharding": "contiguous board ids, no collectives",
                        "result_hist_rank0": hist},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, B),
                          "kernel": "step_kernel<%d>" % n, "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_env_step": ab},
+                         "algorithmic_bytes_per_env_step": ab,
+                         "note": "achieved = 1320 B x env steps / kernel time (SURVEY 8(d) model: full state "
+                                 "read + write per step).  The log-structured state rewrites the planes only "
+                                 "every 8th launch, so the kernel moves ~760 B per env step (traffic, PMC) and "
+                                 "the algorithmic figure can exceed the HBM peak."},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.seed)

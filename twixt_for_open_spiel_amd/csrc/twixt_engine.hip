@@ -207,6 +207,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   prefetch(0, kPf1);
 
   STAMP(1);  // LDS fill + prefetch issue
+#ifdef TWX_SKELETON
+  prefetch(kPf1, CHT);
+  const bool was_reset = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
+  { uint32_t *const sk = lds + (lane << 2) + 2 * G::W * 256; sk[0] += 1u; }
+#else
   uint32_t *const me = lds + (lane << 2);  // this lane's slot inside every chunk row
   // word group i (cells 32i..32i+31) of this lane: me + (i << 9) [+ plane_off(p)]
   uint32_t *const sc = me + CS * 256;      // scalars
@@ -489,6 +494,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   sc[3] = 0u;
   wave_sync();
 
+#endif  // TWX_SKELETON
   // The prefetched batch has had the whole step to arrive: retire its loads HERE, before
   // this batch's stores are issued, so that the wait at the top of the next iteration
   // does not also wait for those stores (loads and stores share one in-order counter).
