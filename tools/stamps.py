@@ -27,8 +27,8 @@ torch.cuda.synchronize()
 env.lib.twx_debug_stamps(buf, 0)
 names = ["loop/prev-store issue", "LDS fill + prefetch issue", "reset/replay", "legal mask", "select",
          "apply", "flood", "wait prefetch", "status store + loop end", "fixed stores", "dirty chunk stores",
-         "reset lanes / compaction stores"]
-tot = sum(buf[i] for i in range(12))
+         "reset lanes / compaction stores", "flood: pass setup", "flood: iterations", "flood: write-back"]
+tot = sum(buf[i] for i in range(15))
 wavesteps = K * (B // 64)
 for i, nm in enumerate(names):
     print("%-28s %9.1f cycles/wave-step  %5.1f %%" % (nm, buf[i] / wavesteps, 100.0 * buf[i] / tot))

@@ -109,7 +109,7 @@ __device__ __forceinline__ int select_bit(uint32_t t, int k) {
 // library): cycles per phase summed over all waves, read with twx_debug_stamps().
 #ifdef TWX_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {0}
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[16] = {0}
 #define STAMP(i)                                                     \
   do {                                                               \
     __builtin_amdgcn_sched_barrier(0);                               \
@@ -123,7 +123,7 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_FLUSH                                                                      \
   do {                                                                                   \
     if (threadIdx.x == 0)                                                                \
-      for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_stamps[i_], st_acc[i_]);              \
+      for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_stamps[i_], st_acc[i_]);              \
   } while (0)
 #else
 #define STAMP_DECL
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   int pa = 0;          // cell the peg finally lands on
   uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
   uint32_t entry = 0;  // journal record of this move
+  uint32_t fast_dirty = 0;  // flag chunk touched by the single-cell fill shortcut
   if (act) {
     // ---- Board::ApplyAction (tb.cc:457-499) ----
     pa = a;
@@ -352,6 +353,23 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       const bool ok = (unsigned)c < (unsigned)N;
       const int o = (ok ? c : 0) * N, sh = o & 31;
       const uint32_t *const g = me + ((o >> 5) << 9);  // next word group: +512 dwords (in bounds: scalars/journal follow)
+#ifdef TWX_COL_B128
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(g), a1 = *reinterpret_cast<const uint4 *>(g + 256);
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(g + 512), b1 = *reinterpret_cast<const uint4 *>(g + 768);
+      auto colv = [&](uint32_t lo, uint32_t hi) -> uint32_t {
+        const uint32_t v = funnel(lo, hi, sh) & kColMask;
+        return ok ? v : 0u;
+      };
+      if (ci >= -2) {
+        wo[ci + 2] = ((colv(player ? a0.y : a0.x, player ? b0.y : b0.x) << 2) >> y) & 0x1fu;
+        ws[ci + 2] = ((colv(a1.z, b1.z) << 2) >> y) & 0x1fu;
+        we[ci + 2] = ((colv(a1.w, b1.w) << 2) >> y) & 0x1fu;
+      }
+      if (ci <= 1) {
+        win[ci + 3] = (((colv(a0.z, b0.z) << 3) >> y) & 0x7fu) | ((((colv(a0.w, b0.w) << 3) >> y) & 0x7fu) << 8) |
+                      ((((colv(a1.x, b1.x) << 3) >> y) & 0x7fu) << 16) | ((((colv(a1.y, b1.y) << 3) >> y) & 0x7fu) << 24);
+      }
+#else
       auto col = [&](int off) -> uint32_t {
         const uint32_t v = funnel(g[off], g[off + 512], sh) & kColMask;
         return ok ? v : 0u;
@@ -367,6 +385,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         for (int e = 0; e < 4; e++) v |= (((col(plane_off(twx::kPlaneLink0 + e)) << 3) >> y) & 0x7fu) << (8 * e);
         win[ci + 3] = v;
       }
+#endif
     }
     uint32_t cand = 0, ts = 0, te = 0, blocked = 0;
 #pragma unroll
@@ -381,6 +400,39 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       blocked |= (hit != 0u ? 1u : 0u) << d;
     }
     const uint32_t linkm = cand & ~blocked;
+    // tb.cc:538-546: inherit START, else END, else remember a neutral neighbour
+    const uint32_t gain_s = linkm & ts, gain_e = linkm & ~ts & te, neutral = linkm & ~ts & ~te;
+    const bool p_s = ((ws[2] >> 2) & 1u) || gain_s;
+    const bool p_e = ((we[2] >> 2) & 1u) || gain_e;
+    uint32_t want = (linkm && neutral) ? ((p_s ? 1u : 0u) | (p_e ? 2u : 0u)) : 0u;  // tb.cc:558-570
+    // Half of all fills flag exactly one cell: the new peg's only unflagged neighbour is a
+    // peg without any other link.  Detect that here, on the pre-move planes, and set the
+    // flag directly; only the other fills go through the wave-cooperative pass below.
+    if (want && !(neutral & (neutral - 1u)) && (!(want & 1u) || (linkm & ~ts) == neutral) &&
+        (!(want & 2u) || (linkm & ~te) == neutral)) {
+      const int d = __ffs((int)neutral) - 1;
+      constexpr uint32_t kDxPack = 0x10013443u, kDyPack = 0x43100134u;  // (offset + 2) per direction, 4 bits each
+      const int tx = x + (int)((kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((kDyPack >> (4 * d)) & 15u) - 2;
+      const int t = tx * N + ty;
+      uint32_t *const gt = me + ((t >> 5) << 9);
+      uint32_t other = (gt[plane_off(2)] | gt[plane_off(3)] | gt[plane_off(4)] | gt[plane_off(5)]) >> (t & 31);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {  // links that END at t: stored at t - off[e]
+        const int sx = tx - twx::kDX[e], sy = ty - twx::kDY[e];
+        const bool valid = sx >= 0 && sy >= 0 && sy < N;
+        const int sc2 = valid ? sx * N + sy : 0;
+        const uint32_t w = me[((sc2 >> 5) << 9) + plane_off(twx::kPlaneLink0 + e)];
+        other |= valid ? (w >> (sc2 & 31)) : 0u;
+      }
+      if (!(other & 1u)) {
+        const uint32_t tbit = 1u << (t & 31);
+        lds_or(gt + oS, (want & 1u) ? tbit : 0u);
+        lds_or(gt + oE, (want & 2u) ? tbit : 0u);
+        fast_dirty = 1u << (t >> 5);
+        want = 0u;
+      }
+    }
+    pend = want;
     {  // tb.cc:532-533: one stored bit per physical link, at its west end
       uint32_t *const g = me + ((pa >> 5) << 9);
       const uint32_t bit = 1u << (pa & 31);
@@ -392,13 +444,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         const int tc = on ? pa + twx::kDX[d] * N + twx::kDY[d] : pa;
         lds_or(me + ((tc >> 5) << 9) + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
       }
-      // tb.cc:538-546: inherit START, else END, else remember a neutral neighbour
-      const uint32_t gain_s = linkm & ts, gain_e = linkm & ~ts & te, neutral = linkm & ~ts & ~te;
-      const bool p_s = ((ws[2] >> 2) & 1u) || gain_s;
-      const bool p_e = ((we[2] >> 2) & 1u) || gain_e;
       lds_or(g + oS, gain_s ? bit : 0u);
       lds_or(g + oE, gain_e ? bit : 0u);
-      if (linkm && neutral) pend = (p_s ? 1u : 0u) | (p_e ? 2u : 0u);  // tb.cc:558-570
       entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
               (gain_s ? 1u << 19 : 0u) | (gain_e ? 1u << 20 : 0u) | (swapnow ? 1u << 21 : 0u);
 
@@ -453,6 +500,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     uint32_t lk[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) lk[e] = col(plane_off(twx::kPlaneLink0 + e));
+    STAMP(12);  // flood: pass setup
 #pragma unroll
     for (int f = 0; f < 2; f++) {
       const bool en = (spend >> f) & 1u;  // uniform per half
@@ -475,6 +523,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         front = fresh;
         if (__ballot(fresh != 0u) == 0ull) break;
       }
+      STAMP(13);  // flood: iterations
       const uint32_t add = flag & ~flag0;
       if (ok && add) {
         uint32_t dirty = 1u << grp;
@@ -486,11 +535,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         lds_or(lds + (src << 2) + CS * 256 + 3, dirty);
       }
       wave_sync();
+      STAMP(14);  // flood: write-back
     }
   }
   wave_sync();
   STAMP(6);  // flood fill
-  const uint32_t dirty = sc[3];
+  const uint32_t dirty = sc[3] | fast_dirty;
   sc[3] = 0u;
   wave_sync();
 
