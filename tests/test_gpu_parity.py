@@ -275,3 +275,24 @@ def test_journal_periods(torch_mod, period, pingpong, monkeypatch):
         if upto in (9, 31):
             assert np.array_equal(env.export_cells().cpu().numpy(), ref["cells"])
     env.close()
+
+
+@pytest.mark.parametrize("n,batch,steps", [(24, 96, 330), (5, 200, 14), (9, 130, 50)])
+def test_observation_sizes(torch_mod, n, batch, steps):
+    """twx_observation (tw.cc:76-132) at other board sizes, mid-game, every board."""
+    import oracle_binding as ob
+    seed = 13
+    env = make_env(n, batch, first=3)
+    for _ in range(steps):
+        env.step_random(seed, True, want_actions=False, want_status=False)
+    obs = env.observation().cpu().numpy()
+    assert obs.shape == (batch, 12, n, n - 2)
+    nz = 0
+    for b in range(batch):
+        bd = ob.Board(n)
+        bd.rollout(seed, 3 + b, steps, True)
+        want = bd.observation()
+        nz += int(want[[1, 2, 3, 4, 5, 7, 8, 9, 10, 11]].sum())
+        assert np.array_equal(obs[b], want), "board %d" % b
+    assert nz > 0  # link and blocked planes are exercised (plane 8 is never set in playthrough.txt)
+    env.close()

@@ -756,39 +756,60 @@ __global__ void cells_kernel(const uint4 *state, Dims d, const int32_t *ids, lon
   o[0] = (uint8_t)colour; o[1] = (uint8_t)links; o[2] = (uint8_t)blk; o[3] = (uint8_t)flags;
 }
 
-// tw.cc:76-132 ObservationTensor: one thread per (board, output element)
-__global__ void observation_kernel(const uint4 *state, Dims d, float *out) {
-  const int N = d.n, per = 12 * N * (N - 2);
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long b = t / per;
-  if (b >= d.batch) return;
-  int r = (int)(t % per);
-  const int plane = r / (N * (N - 2));
-  r -= plane * N * (N - 2);
-  const int tx = r / (N - 2), ty = r % (N - 2);
-  const int colour = plane >= 6 ? 1 : 0, k = plane - 6 * colour;
-  // invert tb.cc:590-597 GetTensorPosition
-  int x, y;
-  if (colour == 0) { y = N - 1 - tx; x = ty + 1; }
-  else { x = N - 1 - tx; y = N - 2 - ty; }
-  const int cell = x * N + y;
-  float v = 0.0f;
-  if (twx::on_board(N, x, y) && plane_bit(state, d, b, colour, cell)) {
-    int links = 0, blk_east = 0;
-    for (int dir = 0; dir < 8; dir++) {
-      const int tx2 = x + twx::kDX[dir], ty2 = y + twx::kDY[dir];
-      if (!twx::on_board(N, tx2, ty2)) continue;
-      const int tc = tx2 * N + ty2;
-      const int lk = (dir < 4) ? plane_bit(state, d, b, twx::kPlaneLink0 + dir, cell)
-                               : plane_bit(state, d, b, twx::kPlaneLink0 + dir - 4, tc);
-      if (lk) links |= 1 << dir;
-      if (dir < 4 && !lk && plane_bit(state, d, b, colour, tc)) blk_east = 1;
+// tw.cc:76-132 ObservationTensor x batch.  Write-bound: 12*N*(N-2) floats per board
+// (25,344 B at N=24) against 592 B of state.  One wavefront per board:
+//   1. the board's 2W+1 state chunks -> LDS (board-contiguous);
+//   2. every cell with a peg -> one 6-bit feature {no-link peg, NNE, ENE, ESE, SSE link,
+//      blocked east} (tw.cc:83-98) stored at its tensor position (tb.cc:590-597: red
+//      (N-1-y, x-1), blue (N-1-x, N-2-y)) in a red and a blue feature plane in LDS;
+//   3. the wave streams the 12 planes out as coalesced 16-byte stores.
+constexpr int kObsMaxPos = TWX_MAX_BOARD_SIZE * (TWX_MAX_BOARD_SIZE - 2);
+__global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restrict__ state, Dims d,
+                                                            float *__restrict__ out) {
+  __shared__ uint4 sst[2 * 18 + 1];
+  __shared__ uint8_t feat[2][kObsMaxPos];
+  const int lane = threadIdx.x, N = d.n, W = d.W, npos = N * (N - 2);
+  const long b = blockIdx.x;
+  for (int c = lane; c < 2 * W + 1; c += kWave) sst[c] = state[(long)c * d.bpad + b];
+  for (int i = lane; i < npos; i += kWave) { feat[0][i] = 0; feat[1][i] = 0; }
+  __syncthreads();
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(sst);
+  auto bit = [&](int p, int cell) -> uint32_t {  // plane p, cell: word 8*(cell>>5)+p of the interleaved layout
+    return (w[8 * (cell >> 5) + p] >> (cell & 31)) & 1u;
+  };
+  for (int cell = lane; cell < N * N; cell += kWave) {
+    const int x = cell / N, y = cell - x * N;
+    const uint32_t red = bit(twx::kPlaneRed, cell), blue = bit(twx::kPlaneBlue, cell);
+    if (!(red | blue)) continue;
+    const int colour = blue ? 1 : 0;
+    uint32_t west = 0, east = 0, blk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t lk = bit(twx::kPlaneLink0 + e, cell);  // link leaving this peg eastwards
+      west |= lk << e;
+      const int tx = x + twx::kDX[e], ty = y + twx::kDY[e];
+      if (twx::on_board(N, tx, ty) && !lk && bit(colour, tx * N + ty)) blk = 1u;  // tb.cc:550-551, derived
+      const int sx = x - twx::kDX[e], sy = y - twx::kDY[e];   // link arriving from the west
+      if (twx::on_board(N, sx, sy)) east |= bit(twx::kPlaneLink0 + e, sx * N + sy);
     }
-    if (k == 0) v = links ? 0.0f : 1.0f;                 // tw.cc:90-93
-    else if (k <= 4) v = (links >> (k - 1)) & 1 ? 1.0f : 0.0f;  // tw.cc:83-89
-    else v = blk_east ? 1.0f : 0.0f;                     // tw.cc:96-98
+    const uint32_t f = ((west | east) ? (west << 1) : 1u) | (blk << 5);  // tw.cc:83-98
+    const int pos = colour ? (N - 1 - x) * (N - 2) + (N - 2 - y) : (N - 1 - y) * (N - 2) + (x - 1);
+    feat[colour][pos] = (uint8_t)f;
   }
-  out[t] = v;
+  __syncthreads();
+  float4 *o = reinterpret_cast<float4 *>(out + b * (long)(12 * npos));
+  const uint32_t magic = (1u << 24) / (uint32_t)npos + 1u;  // e / npos == (e * magic) >> 24 for e < 12*npos <= 6336
+  for (int j = lane; j < 3 * npos; j += kWave) {  // 12*npos floats = 3*npos float4
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int e = 4 * j + q;
+      const int k = (int)(((uint32_t)e * magic) >> 24), pos = e - k * npos;
+      const int colour = k >= 6 ? 1 : 0;
+      v[q] = ((feat[colour][pos] >> (k - 6 * colour)) & 1u) ? 1.0f : 0.0f;
+    }
+    o[j] = make_float4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 template <int N>
@@ -1031,8 +1052,7 @@ int twx_status(const twx_env *e, uint8_t *result, int32_t *move_counter, int8_t 
 int twx_observation(const twx_env *e, float *out, void *stream) {
   if (!e || !out) return fail(TWX_E_ARG, "twx_observation: env or out is NULL");
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
-  const long threads = (long)12 * e->d.n * (e->d.n - 2) * e->d.batch;
-  hipLaunchKernelGGL(observation_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(observation_kernel, dim3((unsigned)e->d.batch), dim3(kWave), 0, (hipStream_t)stream,
                      e->state, e->d, out);
   HIP_TRY(hipGetLastError());
   return TWX_OK;
