@@ -83,6 +83,11 @@ int twx_reset_boards(twx_env *env, const int32_t *ids_dev, int64_t n, void *stre
  * action is not in its legal set (or that is terminal) is left untouched and
  * gets TWX_ST_ILLEGAL.  status_dev[B] may be NULL. */
 int twx_step(twx_env *env, const int32_t *actions_dev, uint8_t *status_dev, void *stream);
+/* same for the n DISTINCT boards listed in ids_dev: actions_dev[n], status_dev[n] (row i
+ * belongs to board ids_dev[i]); every other board is untouched.  This is the batched-leaf
+ * form: an MCTS driver steps exactly the states it expanded. */
+int twx_step_boards(twx_env *env, const int32_t *ids_dev, int64_t n, const int32_t *actions_dev,
+                    uint8_t *status_dev, void *stream);
 
 /* One random-policy env step per board, fused: LegalActions (tw.h:86-90) ->
  * uniform pick -> DoApplyAction.  action = k-th legal action (ascending),
@@ -93,20 +98,29 @@ int twx_step(twx_env *env, const int32_t *actions_dev, uint8_t *status_dev, void
  * may be NULL. */
 int twx_step_random(twx_env *env, uint32_t seed, int auto_reset, int32_t *actions_out_dev,
                     uint8_t *status_dev, void *stream);
+int twx_step_random_boards(twx_env *env, const int32_t *ids_dev, int64_t n, uint32_t seed, int auto_reset,
+                           int32_t *actions_out_dev, uint8_t *status_dev, void *stream);
 
 /* TwixTState::LegalActions as a mask (tw.h:86-90, tb.h:62-64): mask_dev[B][W],
  * bit a set <=> action a legal for the player to move; all zero if terminal.
  * count_dev[B] (int32, may be NULL) = number of legal actions. */
 int twx_legal_mask(const twx_env *env, uint32_t *mask_dev, int32_t *count_dev, void *stream);
+/* same for the n boards listed in ids_dev (NULL = boards 0..n-1): mask_dev[n][W], count_dev[n] */
+int twx_legal_mask_boards(const twx_env *env, const int32_t *ids_dev, int64_t n, uint32_t *mask_dev,
+                          int32_t *count_dev, void *stream);
 
 /* Board::result / move_counter (tb.h:60-61), TwixTState::CurrentPlayer
  * (tw.h:38; -4 = kTerminalPlayerId when terminal).  Any pointer may be NULL. */
 int twx_status(const twx_env *env, uint8_t *result_dev, int32_t *move_counter_dev,
                int8_t *current_player_dev, void *stream);
+int twx_status_boards(const twx_env *env, const int32_t *ids_dev, int64_t n, uint8_t *result_dev,
+                      int32_t *move_counter_dev, int8_t *current_player_dev, void *stream);
 
 /* TwixTState::ObservationTensor x batch (tw.cc:76-132): out_dev[B][12][N][N-2]
  * float32, identical for both observers. */
 int twx_observation(const twx_env *env, float *out_dev, void *stream);
+int twx_observation_boards(const twx_env *env, const int32_t *ids_dev, int64_t n, float *out_dev,
+                           void *stream);
 
 /* TwixTState::Clone (tw.h:80-82): dst board dst_ids[i] := src board
  * src_ids[i].  dst and src may be the same handle but must have equal N. */

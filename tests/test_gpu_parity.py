@@ -296,3 +296,52 @@ def test_observation_sizes(torch_mod, n, batch, steps):
         assert np.array_equal(obs[b], want), "board %d" % b
     assert nz > 0  # link and blocked planes are exercised (plane 8 is never set in playthrough.txt)
     env.close()
+
+
+def test_subset_entry_points(torch_mod):
+    """twx_step_boards / twx_step_random_boards / *_boards queries: only the listed boards
+    move (batched-leaf form), at every journal position, others stay bit-identical."""
+    import oracle_binding as ob
+    torch = torch_mod
+    n, batch, seed = 10, 500, 17
+    env = make_env(n, batch, first=0)
+    rng = np.random.default_rng(3)
+    boards = [ob.Board(n) for _ in range(batch)]
+    for t in range(60):
+        k = int(rng.integers(1, 200))
+        ids = np.sort(rng.choice(batch, size=k, replace=False)).astype(np.int32)
+        if t % 3 == 0:   # random policy on a subset (hash keyed by the global board id)
+            a, st = env.step_random(seed, False, ids=torch.from_numpy(ids))
+            a, st = a.cpu().numpy(), st.cpu().numpy()
+            for j, b in enumerate(ids):
+                ra, rs, _ = boards[b].rollout(seed, int(b), 1, False)
+                assert ra[0] == a[j] and rs[0] == st[j]
+        else:            # caller-chosen actions on a subset
+            acts = np.zeros(k, dtype=np.int32)
+            want = np.zeros(k, dtype=np.uint8)
+            for j, b in enumerate(ids):
+                la = boards[b].legal_actions()
+                acts[j] = la[rng.integers(len(la))] if la and rng.random() > 0.1 else -1
+                try:
+                    boards[b].apply(int(acts[j]))
+                    ill = 0
+                except ValueError:
+                    ill = 4
+                want[j] = boards[b].result | ill | (boards[b].s.swapped << 5)
+            st = env.step(torch.from_numpy(acts), ids=torch.from_numpy(ids)).cpu().numpy()
+            assert np.array_equal(st, want), "step %d" % t
+        if t % 7 == 0:
+            q = np.sort(rng.choice(batch, size=50, replace=False)).astype(np.int32)
+            mask, count = env.legal_mask(torch.from_numpy(q))
+            res, mc, cp = env.status(torch.from_numpy(q))
+            obs = env.observation(torch.from_numpy(q)).cpu().numpy()
+            mask = u32(mask)
+            for j, b in enumerate(q):
+                la = boards[b].legal_actions()
+                assert [a for a in range(n * n) if (mask[j, a >> 5] >> (a & 31)) & 1] == la
+                assert int(count[j]) == len(la) and int(mc[j]) == boards[b].move_counter
+                assert int(cp[j]) == boards[b].current_player()
+                assert np.array_equal(obs[j], boards[b].observation())
+    ref = np.stack([bd.planes() for bd in boards])
+    compare_planes(env, ref, what="subset")
+    env.close()

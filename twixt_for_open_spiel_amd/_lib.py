@@ -42,9 +42,14 @@ def load():
     lib.twx_reset_boards.argtypes = [vp, i32p, C.c_int64, vp]
     lib.twx_step.argtypes = [vp, i32p, u8p, vp]
     lib.twx_step_random.argtypes = [vp, C.c_uint32, C.c_int, i32p, u8p, vp]
+    lib.twx_step_boards.argtypes = [vp, i32p, C.c_int64, i32p, u8p, vp]
+    lib.twx_step_random_boards.argtypes = [vp, i32p, C.c_int64, C.c_uint32, C.c_int, i32p, u8p, vp]
     lib.twx_legal_mask.argtypes = [vp, u32p, i32p, vp]
+    lib.twx_legal_mask_boards.argtypes = [vp, i32p, C.c_int64, u32p, i32p, vp]
     lib.twx_status.argtypes = [vp, u8p, i32p, vp, vp]
+    lib.twx_status_boards.argtypes = [vp, i32p, C.c_int64, u8p, i32p, vp, vp]
     lib.twx_observation.argtypes = [vp, vp, vp]
+    lib.twx_observation_boards.argtypes = [vp, i32p, C.c_int64, vp, vp]
     lib.twx_copy_boards.argtypes = [vp, i32p, vp, i32p, C.c_int64, vp]
     lib.twx_export_state.argtypes = [vp, i32p, C.c_int64, u32p, vp]
     lib.twx_import_state.argtypes = [vp, i32p, C.c_int64, u32p, vp]

@@ -53,45 +53,64 @@ class TwixtBatchEnv:
             t = self._ids(ids)
             _lib.check(self.lib.twx_reset_boards(self._h, _ptr(t), t.numel(), self._stream()))
 
-    # State::ApplyAction -> TwixTState::DoApplyAction (twixt.h:93-104)
-    def step(self, actions, status=None):
+    # State::ApplyAction -> TwixTState::DoApplyAction (twixt.h:93-104); with `ids` only
+    # those (distinct) boards move: actions[i] / status[i] belong to board ids[i]
+    def step(self, actions, status=None, ids=None):
         a = torch.as_tensor(actions, dtype=torch.int32, device=self.device).contiguous()
-        assert a.numel() == self.batch
+        t = self._ids(ids)
+        n = self.batch if t is None else t.numel()
+        assert a.numel() == n
         if status is None:
-            status = torch.empty(self.batch, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.twx_step(self._h, _ptr(a), _ptr(status), self._stream()))
+            status = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if t is None:
+            _lib.check(self.lib.twx_step(self._h, _ptr(a), _ptr(status), self._stream()))
+        else:
+            _lib.check(self.lib.twx_step_boards(self._h, _ptr(t), n, _ptr(a), _ptr(status), self._stream()))
         return status
 
     def step_random(self, seed, auto_reset=True, actions_out=None, status=None, want_actions=True,
-                    want_status=True):
+                    want_status=True, ids=None):
+        t = self._ids(ids)
+        n = self.batch if t is None else t.numel()
         if actions_out is None and want_actions:
-            actions_out = torch.empty(self.batch, dtype=torch.int32, device=self.device)
+            actions_out = torch.empty(n, dtype=torch.int32, device=self.device)
         if status is None and want_status:
-            status = torch.empty(self.batch, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.twx_step_random(self._h, int(seed) & 0xFFFFFFFF, int(bool(auto_reset)),
-                                            _ptr(actions_out), _ptr(status), self._stream()))
+            status = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if t is None:
+            _lib.check(self.lib.twx_step_random(self._h, int(seed) & 0xFFFFFFFF, int(bool(auto_reset)),
+                                                _ptr(actions_out), _ptr(status), self._stream()))
+        else:
+            _lib.check(self.lib.twx_step_random_boards(self._h, _ptr(t), n, int(seed) & 0xFFFFFFFF,
+                                                       int(bool(auto_reset)), _ptr(actions_out), _ptr(status),
+                                                       self._stream()))
         return actions_out, status
 
     # TwixTState::LegalActions (twixt.h:86-90) as masks
-    def legal_mask(self):
-        mask = torch.empty((self.batch, self.mask_words), dtype=torch.int32, device=self.device)
-        count = torch.empty(self.batch, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.twx_legal_mask(self._h, _ptr(mask), _ptr(count), self._stream()))
+    def legal_mask(self, ids=None):
+        t = self._ids(ids)
+        n = self.batch if t is None else t.numel()
+        mask = torch.empty((n, self.mask_words), dtype=torch.int32, device=self.device)
+        count = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.twx_legal_mask_boards(self._h, _ptr(t), n, _ptr(mask), _ptr(count), self._stream()))
         return mask, count
 
     # result / move_counter / CurrentPlayer (twixtboard.h:60-61, twixt.h:38)
-    def status(self):
-        res = torch.empty(self.batch, dtype=torch.uint8, device=self.device)
-        mc = torch.empty(self.batch, dtype=torch.int32, device=self.device)
-        cp = torch.empty(self.batch, dtype=torch.int8, device=self.device)
-        _lib.check(self.lib.twx_status(self._h, _ptr(res), _ptr(mc), _ptr(cp), self._stream()))
+    def status(self, ids=None):
+        t = self._ids(ids)
+        n = self.batch if t is None else t.numel()
+        res = torch.empty(n, dtype=torch.uint8, device=self.device)
+        mc = torch.empty(n, dtype=torch.int32, device=self.device)
+        cp = torch.empty(n, dtype=torch.int8, device=self.device)
+        _lib.check(self.lib.twx_status_boards(self._h, _ptr(t), n, _ptr(res), _ptr(mc), _ptr(cp), self._stream()))
         return res, mc, cp
 
     # TwixTState::ObservationTensor (twixt.cc:101-132)
-    def observation(self):
+    def observation(self, ids=None):
+        t = self._ids(ids)
+        m = self.batch if t is None else t.numel()
         n = self.board_size
-        out = torch.empty((self.batch, 12, n, n - 2), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.twx_observation(self._h, _ptr(out), self._stream()))
+        out = torch.empty((m, 12, n, n - 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.twx_observation_boards(self._h, _ptr(t), m, _ptr(out), self._stream()))
         return out
 
     # TwixTState::Clone (twixt.h:80-82)

@@ -144,13 +144,15 @@ constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush 
 // (kFlagCompact) writes everything and clears the journal.  Lanes that
 // auto-reset write their whole board; lanes whose flood fill changed flag
 // words write those chunks.
-template <int N>
+template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel(uint4 *__restrict__ state, long bpad, long batch,
                                                      const int32_t *__restrict__ actions,
                                                      int32_t *__restrict__ actions_out,
                                                      uint8_t *__restrict__ status, uint32_t seed,
-                                                     uint32_t first_id, int flags, int jpos) {
+                                                     uint32_t first_id, int flags, int jpos,
+                                                     const int32_t *__restrict__ ids_arg, long nsub) {
   using G = twx::Geo<N>;
+  const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
   constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
   constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
                 oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
@@ -163,17 +165,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   const bool compact = (flags & kFlagCompact) != 0;
   const bool flush = (flags & kFlagFlush) != 0;
   const bool random = (flags & kFlagRandom) != 0;
-  const long nbatch = bpad / kWave;  // allocation is padded to a multiple of 64 boards
+  // Rows: the boards this launch works on.  Whole batch: row j is board j (the allocation
+  // is padded to a multiple of 64, padded boards are real storage).  Subset (`ids`): row j
+  // is board ids[j]; lanes past nsub load board 0 and store nothing.
+  const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
 
   // Persistent wave: walks batches idx = blockIdx.x, +gridDim.x, ...  While batch k is
   // processed out of LDS, batch k+1 is already streaming into VGPRs (CHT x 16 B per
   // lane), so HBM latency hides behind the integer work even at one wave per SIMD.
   // kFlagReverse walks the batches backwards: the boards a launch touched last are the
   // ones the next launch touches first (Infinity Cache reuse).
-  auto batch_board = [&](long idx) -> long {
+  auto batch_row = [&](long idx) -> long {
     return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * kWave + lane;
   };
-  STAMP_DECL;
+  auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : 0L) : j; };
+  auto batch_board = [&](long idx) -> long { return row_board(batch_row(idx)); };
   u32x4 nxt[CHT];
   const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
   u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
@@ -187,9 +193,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   }
   for (; idx < nbatch; idx += gridDim.x) {
   STAMP(0);  // loop overhead / previous stores issue
-  const long board = batch_board(idx);
-  const bool inb = board < batch;
-  const int a_ext = (!random && !flush && inb) ? actions[board] : -1;
+  const long row = batch_row(idx);
+  const long board = row_board(row);
+  const bool inb = ids ? (row < nsub) : (board < batch);
+  const bool wr = !ids || inb;  // subset mode: padding lanes must not store
+  const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
 #pragma unroll
   for (int c = 0; c < CHT; c++) ldsv[c * kWave + lane] = nxt[c];
   wave_sync();
@@ -555,15 +563,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   // ---- stream back ----
   if (compact) {
 #pragma unroll
-    for (int c = 0; c < CHT; c++) state[(long)c * bpad + board] = lds4[c * kWave + lane];
+    for (int c = 0; c < CHT; c++)
+      if (wr) state[(long)c * bpad + board] = lds4[c * kWave + lane];
   } else {
-    state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
-    const int jc = CJ + (jpos >> 2);                           // the journal chunk of slot jpos
-    state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+    const int jc = CJ + (jpos >> 2);  // the journal chunk of slot jpos
+    if (wr) {
+      state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
+      state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+    }
     STAMP(9);  // fixed stores (scalars + journal chunk)
     // flag chunks a flood fill changed: every dirty lane walks its own mask, all dirty
     // lanes in parallel (per-lane chunk index), so the loop runs max-popcount times
-    uint32_t dd = was_reset ? 0u : dirty;
+    uint32_t dd = (was_reset || !wr) ? 0u : dirty;
     while (__ballot(dd != 0u)) {
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
@@ -585,9 +596,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       if (illegal) st |= TWX_ST_ILLEGAL;
       if (was_reset) st |= TWX_ST_RESET;
       if (random && !act) st |= TWX_ST_NOOP;
-      status[board] = st;
+      status[row] = st;
     }
-    if (actions_out) actions_out[board] = a;
+    if (actions_out) actions_out[row] = a;
   }
   wave_sync();
   STAMP(8);  // stream back + status
@@ -676,12 +687,14 @@ __global__ void copy_kernel(uint4 *dst, Dims dd, const int32_t *dst_ids, const u
 }
 
 // tw.h:86-90 as a mask: one thread per (board, mask word)
-__global__ void legal_mask_kernel(const uint4 *state, Dims d, const uint32_t *region, uint32_t *mask,
-                                  int32_t *count) {
+__global__ void legal_mask_kernel(const uint4 *state, Dims d, const uint32_t *region, const int32_t *ids,
+                                  long n, uint32_t *mask, int32_t *count) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long b = t % d.batch;
-  const int i = (int)(t / d.batch);
+  const long j = t % n;  // output row
+  const int i = (int)(t / n);
   if (i >= d.W) return;
+  const long b = ids ? ids[j] : j;
+  if (b < 0 || b >= d.batch) return;
   const uint32_t s0 = scalar_word(state, d, b, 0), s1 = scalar_word(state, d, b, 1);
   const uint32_t counter = s0 & 0xffffu, result = s1 & 0xffu;
   const int player = (int)(counter & 1u);
@@ -691,22 +704,24 @@ __global__ void legal_mask_kernel(const uint4 *state, Dims d, const uint32_t *re
     const uint32_t occ = bl | (counter == 1u ? 0u : r);
     mword = region[player * d.W + i] & ~occ;
   }
-  mask[b * d.W + i] = mword;
+  mask[j * d.W + i] = mword;
   if (count) {
     const int pc = __popc(mword);
-    if (pc) atomicAdd(&count[b], pc);
+    if (pc) atomicAdd(&count[j], pc);
   }
 }
 
-__global__ void status_kernel(const uint4 *state, Dims d, uint8_t *result, int32_t *move_counter,
-                              int8_t *current_player) {
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= d.batch) return;
+__global__ void status_kernel(const uint4 *state, Dims d, const int32_t *ids, long n, uint8_t *result,
+                              int32_t *move_counter, int8_t *current_player) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long b = ids ? ids[j] : j;
+  if (b < 0 || b >= d.batch) return;
   const uint4 s = state[(long)(d.CH - 1) * d.bpad + b];
   const uint32_t counter = s.x & 0xffffu, res = s.y & 0xffu;
-  if (result) result[b] = (uint8_t)res;
-  if (move_counter) move_counter[b] = (int32_t)counter;
-  if (current_player) current_player[b] = res ? (int8_t)-4 : (int8_t)(counter & 1u);  // tw.h:99-103
+  if (result) result[j] = (uint8_t)res;
+  if (move_counter) move_counter[j] = (int32_t)counter;
+  if (current_player) current_player[j] = res ? (int8_t)-4 : (int8_t)(counter & 1u);  // tw.h:99-103
 }
 
 __device__ __forceinline__ int plane_bit(const uint4 *state, const Dims &d, long b, int plane, int cell) {
@@ -765,11 +780,14 @@ __global__ void cells_kernel(const uint4 *state, Dims d, const int32_t *ids, lon
 //   3. the wave streams the 12 planes out as coalesced 16-byte stores.
 constexpr int kObsMaxPos = TWX_MAX_BOARD_SIZE * (TWX_MAX_BOARD_SIZE - 2);
 __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restrict__ state, Dims d,
+                                                            const int32_t *__restrict__ ids,
                                                             float *__restrict__ out) {
   __shared__ uint4 sst[2 * 18 + 1];
   __shared__ uint8_t feat[2][kObsMaxPos];
   const int lane = threadIdx.x, N = d.n, W = d.W, npos = N * (N - 2);
-  const long b = blockIdx.x;
+  const long j = blockIdx.x;  // output row
+  long b = ids ? ids[j] : j;
+  if (b < 0 || b >= d.batch) b = 0;  // host validated; keep the block's barriers uniform
   for (int c = lane; c < 2 * W + 1; c += kWave) sst[c] = state[(long)c * d.bpad + b];
   for (int i = lane; i < npos; i += kWave) { feat[0][i] = 0; feat[1][i] = 0; }
   __syncthreads();
@@ -797,7 +815,7 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
     feat[colour][pos] = (uint8_t)f;
   }
   __syncthreads();
-  float4 *o = reinterpret_cast<float4 *>(out + b * (long)(12 * npos));
+  float4 *o = reinterpret_cast<float4 *>(out + j * (long)(12 * npos));
   const uint32_t magic = (1u << 24) / (uint32_t)npos + 1u;  // e / npos == (e * magic) >> 24 for e < 12*npos <= 6336
   for (int j = lane; j < 3 * npos; j += kWave) {  // 12*npos floats = 3*npos float4
     float v[4];
@@ -815,17 +833,21 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                       hipStream_t s) {
+                       const int32_t *ids, long nsub, hipStream_t s) {
   constexpr size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // 39 KiB at N=24: 4 waves per CU
-  const long nbatch = bpad / kWave;
+  const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
-  hipLaunchKernelGGL(step_kernel<N>, dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
-                     batch, actions, actions_out, status, seed, first_id, flags, jpos);
+  if (ids)
+    hipLaunchKernelGGL((step_kernel<N, true>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
+                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub);
+  else
+    hipLaunchKernelGGL((step_kernel<N, false>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
+                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub);
   return hipGetLastError();
 }
 
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, hipStream_t);
+                              int, int, int, const int32_t *, long, hipStream_t);
 
 template <int N>
 struct StepTable {
@@ -877,14 +899,20 @@ int env_int(const char *name, int dflt, int lo, int hi) {
   return x < lo ? lo : x > hi ? hi : x;
 }
 
-// one env step (or a flush) on every board; maintains the journal position
+// one env step (or a flush) on every board, or on the `nsub` boards listed in `ids`;
+// maintains the journal position
 int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *status, uint32_t seed,
-             int flags, hipStream_t s) {
+             int flags, const int32_t *ids, long nsub, hipStream_t s) {
   const bool flush = (flags & kFlagFlush) != 0;
-  if (flush || e->jpos == e->period - 1) flags |= kFlagCompact;
-  if (e->pingpong && (e->launches & 1)) flags |= kFlagReverse;
+  if (ids && e->jpos == e->period - 1) {
+    // a compaction must cover every board: do it as a flush, then step the subset on an
+    // empty journal
+    if (int rc = run_step(e, nullptr, nullptr, nullptr, 0u, kFlagFlush, nullptr, 0, s)) return rc;
+  }
+  if (flush || (!ids && e->jpos == e->period - 1)) flags |= kFlagCompact;
+  if (e->pingpong && !ids && (e->launches & 1)) flags |= kFlagReverse;
   HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                           (uint32_t)e->first_id, flags, e->jpos, e->waves, s));
+                           (uint32_t)e->first_id, flags, e->jpos, e->waves, ids, nsub, s));
   e->jpos = (flags & kFlagCompact) ? 0 : e->jpos + 1;
   e->launches++;
   return TWX_OK;
@@ -894,7 +922,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
 int materialise(const twx_env *ce, hipStream_t s) {
   twx_env *e = const_cast<twx_env *>(ce);
   if (e->jpos == 0) return TWX_OK;
-  return run_step(e, nullptr, nullptr, nullptr, 0u, kFlagFlush, s);
+  return run_step(e, nullptr, nullptr, nullptr, 0u, kFlagFlush, nullptr, 0, s);
 }
 
 }  // namespace
@@ -1017,24 +1045,57 @@ int twx_reset_boards(twx_env *e, const int32_t *ids, int64_t n, void *stream) {
 
 int twx_step(twx_env *e, const int32_t *actions, uint8_t *status, void *stream) {
   if (!e || !actions) return fail(TWX_E_ARG, "twx_step: env or actions is NULL");
-  return run_step(e, actions, nullptr, status, 0u, 0, (hipStream_t)stream);
+  return run_step(e, actions, nullptr, status, 0u, 0, nullptr, 0, (hipStream_t)stream);
+}
+
+int twx_step_boards(twx_env *e, const int32_t *ids, int64_t n, const int32_t *actions, uint8_t *status,
+                    void *stream) {
+  if (!e || !ids || !actions || n < 0) return fail(TWX_E_ARG, "twx_step_boards: bad argument");
+  if (n == 0) return TWX_OK;
+  return run_step(e, actions, nullptr, status, 0u, 0, ids, (long)n, (hipStream_t)stream);
+}
+
+int twx_step_random_boards(twx_env *e, const int32_t *ids, int64_t n, uint32_t seed, int auto_reset,
+                           int32_t *actions_out, uint8_t *status, void *stream) {
+  if (!e || !ids || n < 0) return fail(TWX_E_ARG, "twx_step_random_boards: bad argument");
+  if (n == 0) return TWX_OK;
+  const int flags = kFlagRandom | (auto_reset ? kFlagAutoReset : 0);
+  return run_step(e, nullptr, actions_out, status, seed, flags, ids, (long)n, (hipStream_t)stream);
 }
 
 int twx_step_random(twx_env *e, uint32_t seed, int auto_reset, int32_t *actions_out, uint8_t *status,
                     void *stream) {
   if (!e) return fail(TWX_E_ARG, "twx_step_random: env is NULL");
   const int flags = kFlagRandom | (auto_reset ? kFlagAutoReset : 0);
-  return run_step(e, nullptr, actions_out, status, seed, flags, (hipStream_t)stream);
+  return run_step(e, nullptr, actions_out, status, seed, flags, nullptr, 0, (hipStream_t)stream);
+}
+
+int twx_legal_mask_boards(const twx_env *e, const int32_t *ids, int64_t n, uint32_t *mask, int32_t *count,
+                          void *stream) {
+  if (!e || !mask || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_legal_mask: bad argument");
+  if (n == 0) return TWX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = materialise(e, s)) return rc;
+  if (count) HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t) * n, s));
+  const long threads = (long)e->d.W * n;
+  hipLaunchKernelGGL(legal_mask_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, e->state, e->d,
+                     e->tables, ids, (long)n, mask, count);
+  HIP_TRY(hipGetLastError());
+  return TWX_OK;
 }
 
 int twx_legal_mask(const twx_env *e, uint32_t *mask, int32_t *count, void *stream) {
-  if (!e || !mask) return fail(TWX_E_ARG, "twx_legal_mask: env or mask is NULL");
-  hipStream_t s = (hipStream_t)stream;
-  if (int rc = materialise(e, s)) return rc;
-  if (count) HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t) * e->d.batch, s));
-  const long threads = (long)e->d.W * e->d.batch;
-  hipLaunchKernelGGL(legal_mask_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, e->state, e->d,
-                     e->tables, mask, count);
+  if (!e) return fail(TWX_E_ARG, "twx_legal_mask: env is NULL");
+  return twx_legal_mask_boards(e, nullptr, e->d.batch, mask, count, stream);
+}
+
+int twx_status_boards(const twx_env *e, const int32_t *ids, int64_t n, uint8_t *result, int32_t *move_counter,
+                      int8_t *current_player, void *stream) {
+  if (!e || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_status: bad argument");
+  if (n == 0) return TWX_OK;
+  // (scalars are written by every launch: no materialisation needed)
+  hipLaunchKernelGGL(status_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, e->state, e->d,
+                     ids, (long)n, result, move_counter, current_player);
   HIP_TRY(hipGetLastError());
   return TWX_OK;
 }
@@ -1042,20 +1103,22 @@ int twx_legal_mask(const twx_env *e, uint32_t *mask, int32_t *count, void *strea
 int twx_status(const twx_env *e, uint8_t *result, int32_t *move_counter, int8_t *current_player,
                void *stream) {
   if (!e) return fail(TWX_E_ARG, "twx_status: env is NULL");
-  // (scalars are written by every launch: no materialisation needed)
-  hipLaunchKernelGGL(status_kernel, dim3(blocks_for(e->d.batch, 256)), dim3(256), 0, (hipStream_t)stream,
-                     e->state, e->d, result, move_counter, current_player);
+  return twx_status_boards(e, nullptr, e->d.batch, result, move_counter, current_player, stream);
+}
+
+int twx_observation_boards(const twx_env *e, const int32_t *ids, int64_t n, float *out, void *stream) {
+  if (!e || !out || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_observation: bad argument");
+  if (n == 0) return TWX_OK;
+  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
+  hipLaunchKernelGGL(observation_kernel, dim3((unsigned)n), dim3(kWave), 0, (hipStream_t)stream, e->state, e->d,
+                     ids, out);
   HIP_TRY(hipGetLastError());
   return TWX_OK;
 }
 
 int twx_observation(const twx_env *e, float *out, void *stream) {
-  if (!e || !out) return fail(TWX_E_ARG, "twx_observation: env or out is NULL");
-  if (int rc = materialise(e, (hipStream_t)stream)) return rc;
-  hipLaunchKernelGGL(observation_kernel, dim3((unsigned)e->d.batch), dim3(kWave), 0, (hipStream_t)stream,
-                     e->state, e->d, out);
-  HIP_TRY(hipGetLastError());
-  return TWX_OK;
+  if (!e) return fail(TWX_E_ARG, "twx_observation: env is NULL");
+  return twx_observation_boards(e, nullptr, e->d.batch, out, stream);
 }
 
 int twx_copy_boards(twx_env *dst, const int32_t *dst_ids, const twx_env *src, const int32_t *src_ids,
