@@ -142,6 +142,13 @@ int twx_import_state(twx_env *env, const int32_t *ids_dev, int64_t n, const uint
 int twx_export_cells(const twx_env *env, const int32_t *ids_dev, int64_t n, uint8_t *out_dev,
                      void *stream);
 
+/* Host-only text (no device work).  Board::ToString (tb.cc:278-335) from the HOST copy of
+ * one board's twx_export_cells bytes; returns the full length (like snprintf), writes at
+ * most cap-1 characters + NUL.  TwixTState::ActionToString (tw.cc:67-74). */
+int twx_cells_to_string(const uint8_t *cells_host, int board_size, int ansi_color_output, int swapped,
+                        int result, char *buf, int cap);
+int twx_action_to_string(int board_size, int player, int64_t action, char *buf, int cap);
+
 const char *twx_last_error(void);
 
 #ifdef __cplusplus

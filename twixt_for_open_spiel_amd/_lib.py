@@ -54,6 +54,8 @@ def load():
     lib.twx_export_state.argtypes = [vp, i32p, C.c_int64, u32p, vp]
     lib.twx_import_state.argtypes = [vp, i32p, C.c_int64, u32p, vp]
     lib.twx_export_cells.argtypes = [vp, i32p, C.c_int64, u8p, vp]
+    lib.twx_cells_to_string.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lib.twx_action_to_string.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int]
     lib.twx_last_error.argtypes = []
     lib.twx_last_error.restype = C.c_char_p
     _lib = lib

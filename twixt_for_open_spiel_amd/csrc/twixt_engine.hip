@@ -22,12 +22,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
 
 #include "../../include/twixt_hip.h"
 #include "twixt_geom.h"
+#include "twixt_text.h"
 
 namespace {
 
@@ -941,6 +943,28 @@ extern "C" int twx_debug_stamps(unsigned long long *out, int reset) {
 extern "C" {
 
 const char *twx_last_error(void) { return g_err.c_str(); }
+
+// Host-only text helpers (no device work): Board::ToString / ActionToString
+int twx_cells_to_string(const uint8_t *cells_host, int n, int ansi, int swapped, int result, char *buf,
+                        int cap) {
+  if (!cells_host || n < TWX_MIN_BOARD_SIZE || n > TWX_MAX_BOARD_SIZE || (cap > 0 && !buf))
+    return fail(TWX_E_ARG, "twx_cells_to_string: bad argument");
+  const std::string s = twx::text::BoardToString(cells_host, n, ansi != 0, swapped != 0, result);
+  if (cap > 0) {
+    const size_t k = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1;
+    memcpy(buf, s.data(), k);
+    buf[k] = 0;
+  }
+  return (int)s.size();
+}
+
+int twx_action_to_string(int n, int player, int64_t action, char *buf, int cap) {
+  if (!buf || cap < 8 || n < TWX_MIN_BOARD_SIZE || n > TWX_MAX_BOARD_SIZE || action < 0 || action >= n * n)
+    return fail(TWX_E_ARG, "twx_action_to_string: bad argument");
+  const std::string s = twx::text::ActionToString(n, player, (long)action);
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
 
 int twx_state_words(int n) {
   if (n < TWX_MIN_BOARD_SIZE || n > TWX_MAX_BOARD_SIZE) return TWX_E_SIZE;
