@@ -101,6 +101,15 @@ int twx_step_random(twx_env *env, uint32_t seed, int auto_reset, int32_t *action
 int twx_step_random_boards(twx_env *env, const int32_t *ids_dev, int64_t n, uint32_t seed, int auto_reset,
                            int32_t *actions_out_dev, uint8_t *status_dev, void *stream);
 
+/* A whole random play-out per board in ONE launch (what RandomRolloutEvaluator / example do
+ * with LegalActions + ApplyAction in a loop): every board (ids_dev == NULL, n = 0 or B) or
+ * every listed board plays the random policy of twx_step_random, without auto-reset, until
+ * it is terminal or max_steps moves were made; the state stays on chip between moves.
+ * Identical to max_steps calls of twx_step_random(auto_reset = 0).  status_dev[n or B] gets
+ * the final status byte (may be NULL). */
+int twx_random_rollout(twx_env *env, const int32_t *ids_dev, int64_t n, uint32_t seed, int max_steps,
+                       uint8_t *status_dev, void *stream);
+
 /* TwixTState::LegalActions as a mask (tw.h:86-90, tb.h:62-64): mask_dev[B][W],
  * bit a set <=> action a legal for the player to move; all zero if terminal.
  * count_dev[B] (int32, may be NULL) = number of legal actions. */

@@ -345,3 +345,33 @@ def test_subset_entry_points(torch_mod):
     ref = np.stack([bd.planes() for bd in boards])
     compare_planes(env, ref, what="subset")
     env.close()
+
+
+@pytest.mark.parametrize("n,batch", [(8, 1500), (12, 700), (24, 200)])
+def test_fused_rollout(torch_mod, n, batch):
+    """twx_random_rollout: whole play-outs in one launch == the same number of
+    twx_step_random(auto_reset=0) calls == the oracle, on all boards and on a subset."""
+    import oracle_binding as ob
+    torch = torch_mod
+    seed, maxlen = 23, n * n - 3
+    env = make_env(n, batch, first=40)
+    for _ in range(5):   # start from a position with a journal in flight
+        env.step_random(seed, False, want_actions=False, want_status=False)
+    st = env.random_rollout(seed).cpu().numpy()
+    ref = ob.rollout_batch(n, seed, 40, batch, maxlen + 5, False, want_cells=True, want_trace=True)
+    compare_planes(env, ref["planes"], what="rollout")
+    assert np.array_equal(env.export_cells().cpu().numpy(), ref["cells"])
+    assert np.array_equal(st & 3, ref["planes"][:, -3] & 3) and (st & 3).all()  # every game finished
+    # bounded rollout of a subset from the initial position
+    env.reset()
+    ids = np.arange(3, batch, 7, dtype=np.int32)
+    env.random_rollout(seed, max_steps=9, ids=torch.from_numpy(ids))
+    got = u32(env.export_state())
+    fresh = ob.Board(n).planes()
+    for b in range(batch):
+        if b in set(ids.tolist()):
+            want = ob.rollout_batch(n, seed, 40 + b, 1, 9, False)["planes"][0]
+        else:
+            want = fresh
+        assert np.array_equal(got[b, :-2], want[:-2]), "board %d" % b
+    env.close()

@@ -44,6 +44,7 @@ def load():
     lib.twx_step_random.argtypes = [vp, C.c_uint32, C.c_int, i32p, u8p, vp]
     lib.twx_step_boards.argtypes = [vp, i32p, C.c_int64, i32p, u8p, vp]
     lib.twx_step_random_boards.argtypes = [vp, i32p, C.c_int64, C.c_uint32, C.c_int, i32p, u8p, vp]
+    lib.twx_random_rollout.argtypes = [vp, i32p, C.c_int64, C.c_uint32, C.c_int, u8p, vp]
     lib.twx_legal_mask.argtypes = [vp, u32p, i32p, vp]
     lib.twx_legal_mask_boards.argtypes = [vp, i32p, C.c_int64, u32p, i32p, vp]
     lib.twx_status.argtypes = [vp, u8p, i32p, vp, vp]

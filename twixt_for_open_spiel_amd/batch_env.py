@@ -85,6 +85,17 @@ class TwixtBatchEnv:
                                                        self._stream()))
         return actions_out, status
 
+    # whole random play-outs in one launch (RandomRolloutEvaluator's inner loop)
+    def random_rollout(self, seed, max_steps=None, ids=None, want_status=True):
+        t = self._ids(ids)
+        n = self.batch if t is None else t.numel()
+        if max_steps is None:
+            max_steps = self.board_size * self.board_size - 3  # MaxGameLength (twixt.h:136-139)
+        status = torch.empty(n, dtype=torch.uint8, device=self.device) if want_status else None
+        _lib.check(self.lib.twx_random_rollout(self._h, _ptr(t), 0 if t is None else n, int(seed) & 0xFFFFFFFF,
+                                               int(max_steps), _ptr(status), self._stream()))
+        return status
+
     # TwixTState::LegalActions (twixt.h:86-90) as masks
     def legal_mask(self, ids=None):
         t = self._ids(ids)

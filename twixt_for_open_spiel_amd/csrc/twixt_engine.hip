@@ -152,7 +152,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
                                                      int32_t *__restrict__ actions_out,
                                                      uint8_t *__restrict__ status, uint32_t seed,
                                                      uint32_t first_id, int flags, int jpos,
-                                                     const int32_t *__restrict__ ids_arg, long nsub) {
+                                                     const int32_t *__restrict__ ids_arg, long nsub,
+                                                     int rsteps) {
   using G = twx::Geo<N>;
   const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
   constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
@@ -273,7 +274,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   wave_sync();
 
   STAMP(2);  // reset / journal replay
-  prefetch(kPf1, kPf2);
+  int a = -1;
+  bool act = false, illegal = false;
+  uint32_t dirty = 0u;
+  // rsteps == 1: one env step.  rsteps > 1 (twx_random_rollout): up to rsteps moves per
+  // board with the state staying in LDS, until every board of the batch is terminal.
+  for (int rs = 0; rs < rsteps; rs++) {
+  if (rs == 0) prefetch(kPf1, kPf2);
   const int player = (int)(counter & 1u);
   const bool open = (result == 0u);
 
@@ -299,9 +306,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 
   STAMP(3);  // legal mask + counts
   // ---- choose / validate the action ----
-  int a = -1;
-  bool act = inb && open && !flush;
-  bool illegal = false;
+  a = -1;
+  act = inb && open && !flush;
+  illegal = false;
   if (random) {
     act = act && cnt > 0;
     const uint32_t h = twx::policy_hash(seed, first_id + (uint32_t)board, episode, counter);
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   }
 
   STAMP(4);  // action select
-  prefetch(kPf2, CHT);
+  if (rs == 0) prefetch(kPf2, CHT);
   int pa = 0;          // cell the peg finally lands on
   uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
   uint32_t entry = 0;  // journal record of this move
@@ -550,9 +557,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   }
   wave_sync();
   STAMP(6);  // flood fill
-  const uint32_t dirty = sc[3] | fast_dirty;
+  dirty |= sc[3] | fast_dirty;
   sc[3] = 0u;
   wave_sync();
+  if (rs + 1 < rsteps && __ballot(inb && result == 0u) == 0ull) break;  // everyone finished
+  }  // rollout steps
 
 #endif  // TWX_SKELETON
   // The prefetched batch has had the whole step to arrive: retire its loads HERE, before
@@ -835,21 +844,21 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                       const int32_t *ids, long nsub, hipStream_t s) {
+                       const int32_t *ids, long nsub, int rsteps, hipStream_t s) {
   constexpr size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // 39 KiB at N=24: 4 waves per CU
   const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
   if (ids)
     hipLaunchKernelGGL((step_kernel<N, true>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
-                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub);
+                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps);
   else
     hipLaunchKernelGGL((step_kernel<N, false>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
-                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub);
+                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps);
   return hipGetLastError();
 }
 
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, const int32_t *, long, hipStream_t);
+                              int, int, int, const int32_t *, long, int, hipStream_t);
 
 template <int N>
 struct StepTable {
@@ -904,7 +913,7 @@ int env_int(const char *name, int dflt, int lo, int hi) {
 // one env step (or a flush) on every board, or on the `nsub` boards listed in `ids`;
 // maintains the journal position
 int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *status, uint32_t seed,
-             int flags, const int32_t *ids, long nsub, hipStream_t s) {
+             int flags, const int32_t *ids, long nsub, hipStream_t s, int rsteps = 1) {
   const bool flush = (flags & kFlagFlush) != 0;
   if (ids && e->jpos == e->period - 1) {
     // a compaction must cover every board: do it as a flush, then step the subset on an
@@ -914,7 +923,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   if (flush || (!ids && e->jpos == e->period - 1)) flags |= kFlagCompact;
   if (e->pingpong && !ids && (e->launches & 1)) flags |= kFlagReverse;
   HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                           (uint32_t)e->first_id, flags, e->jpos, e->waves, ids, nsub, s));
+                           (uint32_t)e->first_id, flags, e->jpos, e->waves, ids, nsub, rsteps, s));
   e->jpos = (flags & kFlagCompact) ? 0 : e->jpos + 1;
   e->launches++;
   return TWX_OK;
@@ -1085,6 +1094,18 @@ int twx_step_random_boards(twx_env *e, const int32_t *ids, int64_t n, uint32_t s
   if (n == 0) return TWX_OK;
   const int flags = kFlagRandom | (auto_reset ? kFlagAutoReset : 0);
   return run_step(e, nullptr, actions_out, status, seed, flags, ids, (long)n, (hipStream_t)stream);
+}
+
+int twx_random_rollout(twx_env *e, const int32_t *ids, int64_t n, uint32_t seed, int max_steps, uint8_t *status,
+                       void *stream) {
+  if (!e || n < 0 || max_steps < 1 || (!ids && n != 0 && n != e->d.batch))
+    return fail(TWX_E_ARG, "twx_random_rollout: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = materialise(e, s)) return rc;  // the rollout works on materialised planes
+  if (ids && n == 0) return TWX_OK;
+  // one launch: every board plays on, out of LDS, until it is terminal or max_steps moves
+  // were made; written back as a compaction (journal stays empty)
+  return run_step(e, nullptr, nullptr, status, seed, kFlagRandom | kFlagCompact, ids, ids ? (long)n : 0, s, max_steps);
 }
 
 int twx_step_random(twx_env *e, uint32_t seed, int auto_reset, int32_t *actions_out, uint8_t *status,
