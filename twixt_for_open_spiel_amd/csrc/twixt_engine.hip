@@ -62,7 +62,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte v
 // HBM: state[chunk][board] (uint4); LDS image of a wave: [chunk][lane] (uint4),
 // so chunk c of lane l starts at dword c*256 + l*4.
 // ---------------------------------------------------------------------------
-__device__ __host__ constexpr int plane_off(int p) { return (p >> 2) * 256 + (p & 3); }
 
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_or_b32
@@ -146,8 +145,8 @@ constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush 
 // (kFlagCompact) writes everything and clears the journal.  Lanes that
 // auto-reset write their whole board; lanes whose flood fill changed flag
 // words write those chunks.
-template <int N, bool SUB>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel(uint4 *__restrict__ state, long bpad, long batch,
+template <int N, bool SUB, int BPW>
+__device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, long batch,
                                                      const int32_t *__restrict__ actions,
                                                      int32_t *__restrict__ actions_out,
                                                      uint8_t *__restrict__ status, uint32_t seed,
@@ -157,6 +156,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   using G = twx::Geo<N>;
   const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
   constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
+  // BPW boards per wave (64: one per lane; 32: both 32-lane halves run the same per-board
+  // logic on the same board -- every LDS update is an idempotent OR / AND / equal-value
+  // store -- while fills, prefetches and stores are split by half: the LDS image is half
+  // as big, so 8 waves fit a CU instead of 4).  RS = dwords per chunk row of the image.
+  static_assert(BPW == 64 || BPW == 32, "boards per wave");
+  constexpr int RS = BPW * 4, GS = 2 * RS;  // chunk-row / word-group stride in dwords
+  constexpr int NJ = (BPW == 64) ? CHT : (CHT + 1) / 2;  // 16-byte registers a lane prefetches
+#define plane_off(p) ((((p) >> 2) * RS) + ((p) & 3))
   constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
                 oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
   constexpr uint32_t kColMask = (1u << N) - 1u;
@@ -165,13 +172,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
 
   const int lane = threadIdx.x;
+  const int half = (BPW == 64) ? 0 : (lane >> 5);  // which chunk parity this lane moves
+  const int bl = lane & (BPW - 1);                 // board slot of this lane inside the batch
+  auto chunk_of = [&](int j) -> int { return (BPW == 64) ? j : 2 * j + half; };
   const bool compact = (flags & kFlagCompact) != 0;
   const bool flush = (flags & kFlagFlush) != 0;
   const bool random = (flags & kFlagRandom) != 0;
   // Rows: the boards this launch works on.  Whole batch: row j is board j (the allocation
   // is padded to a multiple of 64, padded boards are real storage).  Subset (`ids`): row j
   // is board ids[j]; lanes past nsub load board 0 and store nothing.
-  const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
+  const long nbatch = ids ? (nsub + BPW - 1) / BPW : bpad / BPW;
 
   // Persistent wave: walks batches idx = blockIdx.x, +gridDim.x, ...  While batch k is
   // processed out of LDS, batch k+1 is already streaming into VGPRs (CHT x 16 B per
@@ -179,20 +189,20 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   // kFlagReverse walks the batches backwards: the boards a launch touched last are the
   // ones the next launch touches first (Infinity Cache reuse).
   auto batch_row = [&](long idx) -> long {
-    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * kWave + lane;
+    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * BPW + bl;
   };
   auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : 0L) : j; };
   auto batch_board = [&](long idx) -> long { return row_board(batch_row(idx)); };
-  u32x4 nxt[CHT];
+  u32x4 nxt[NJ];
   const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
   u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
   long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
   {
     const long b0 = batch_board(idx);
 #pragma unroll
-    for (int c = 0; c < CHT; c++) nxt[c] = gstate[(long)c * bpad + b0];
+    for (int j = 0; j < NJ; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b0];
 #pragma unroll
-    for (int c = 0; c < CHT; c++) asm volatile("" ::"v"(nxt[c]));  // first batch: nothing to overlap with
+    for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
   for (; idx < nbatch; idx += gridDim.x) {
   STAMP(0);  // loop overhead / previous stores issue
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   const bool wr = !ids || inb;  // subset mode: padding lanes must not store
   const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
 #pragma unroll
-  for (int c = 0; c < CHT; c++) ldsv[c * kWave + lane] = nxt[c];
+  for (int j = 0; j < NJ; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
   wave_sync();
   // prefetch of the next batch, issued in three slices between the phases below so
   // that the wave never sits behind a 39-deep burst in its memory-issue queue (the
@@ -211,22 +221,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   auto prefetch = [&](int c0, int c1) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = c0; c < c1; c++) nxt[c] = gstate[(long)c * bpad + b1];
+    for (int j = c0; j < c1; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b1];
     __builtin_amdgcn_sched_barrier(0);
   };
-  constexpr int kPf1 = CHT / 3, kPf2 = 2 * CHT / 3;
+  constexpr int kPf1 = NJ / 3, kPf2 = 2 * NJ / 3;
   prefetch(0, kPf1);
 
   STAMP(1);  // LDS fill + prefetch issue
 #ifdef TWX_SKELETON
-  prefetch(kPf1, CHT);
+  prefetch(kPf1, NJ);
   const bool was_reset = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
-  { uint32_t *const sk = lds + (lane << 2) + 2 * G::W * 256; sk[0] += 1u; }
+  { uint32_t *const sk = lds + (bl << 2) + 2 * G::W * RS; sk[0] += 1u; }
 #else
-  uint32_t *const me = lds + (lane << 2);  // this lane's slot inside every chunk row
-  // word group i (cells 32i..32i+31) of this lane: me + (i << 9) [+ plane_off(p)]
-  uint32_t *const sc = me + CS * 256;      // scalars
-  uint32_t *const jn = me + CJ * 256;      // journal slot s at jn[(s >> 2) * 256 + (s & 3)]
+  uint32_t *const me = lds + (bl << 2);  // this board's slot inside every chunk row
+  // word group i (cells 32i..32i+31) of this board: me + i * GS [+ plane_off(p)]
+  uint32_t *const sc = me + CS * RS;     // scalars
+  uint32_t *const jn = me + CJ * RS;     // journal slot s at jn[(s >> 2) * RS + (s & 3)]
 
   const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
   uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
@@ -238,12 +248,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in place ----
 #pragma unroll
     for (int i = 0; i < W; i++) {
-      *reinterpret_cast<uint4 *>(me + (i << 9)) = make_uint4(0u, 0u, 0u, 0u);
-      *reinterpret_cast<uint4 *>(me + (i << 9) + 256) =
+      *reinterpret_cast<uint4 *>(me + i * GS) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4 *>(me + i * GS + RS) =
           make_uint4(0u, 0u, G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
     }
     *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4 *>(jn + 256) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(jn + RS) = make_uint4(0u, 0u, 0u, 0u);
     counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
     was_reset = true;
   } else {
@@ -251,11 +261,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++) {
       if (s < jpos) {  // wave-uniform
-        const uint32_t e = jn[(s >> 2) * 256 + (s & 3)];
+        const uint32_t e = jn[(s >> 2) * RS + (s & 3)];
         const int cell = (int)(e & 1023u);
         const uint32_t bit = (e & twx::kJValid) ? (1u << (cell & 31)) : 0u;  // empty record: every OR is a no-op
-        uint32_t *const g = me + ((cell >> 5) << 9);
-        if (e & (1u << 21)) lds_and(me + ((move_one >> 5) << 9) + oR, ~(1u << (move_one & 31)));  // swap: tb.cc:450-455
+        uint32_t *const g = me + (cell >> 5) * GS;
+        if (e & (1u << 21)) lds_and(me + (move_one >> 5) * GS + oR, ~(1u << (move_one & 31)));  // swap: tb.cc:450-455
         lds_or(g + oR + ((e >> 10) & 1u), bit);  // peg: red / blue words are adjacent
 #pragma unroll
         for (int d = 0; d < 4; d++)  // links whose west end is this peg
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
           const bool on = (e & (1u << (11 + d))) != 0u;
           const int tc = on ? cell + twx::kDX[d] * N + twx::kDY[d] : cell;
-          lds_or(me + ((tc >> 5) << 9) + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
+          lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
         }
         lds_or(g + oS, (e & (1u << 19)) ? bit : 0u);
         lds_or(g + oE, (e & (1u << 20)) ? bit : 0u);
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   int cnt_r = 0, cnt_b = 0;
 #pragma unroll
   for (int i = 0; i < W; i++) {
-    const uint2 rb = *reinterpret_cast<const uint2 *>(me + (i << 9));
+    const uint2 rb = *reinterpret_cast<const uint2 *>(me + i * GS);
     const uint32_t occ = rb.x | rb.y;
     uint32_t mr = G::tab.region[0][i] & ~occ;
     uint32_t mb = G::tab.region[1][i] & ~occ;
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       const int ax = a / N, ay = a - ax * N;
       const bool inreg = player ? (ay >= 1 && ay <= N - 2) : (ax >= 1 && ax <= N - 2);
       const uint32_t bit = 1u << (a & 31);
-      const uint2 rb = *reinterpret_cast<const uint2 *>(me + ((a >> 5) << 9));
+      const uint2 rb = *reinterpret_cast<const uint2 *>(me + (a >> 5) * GS);
       const bool occ = ((rb.y & bit) != 0u) || (counter != 1u && (rb.x & bit) != 0u);
       legal = inreg && !occ;
     }
@@ -352,12 +362,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     const bool swapnow = (counter == 1u) && ((uint32_t)a == move_one);
     if (swapnow) {  // tb.cc:462-473: undo red's first peg, rotate 90 degrees
       swapped = 1u;
-      lds_and(me + ((a >> 5) << 9) + oR, ~(1u << (a & 31)));
+      lds_and(me + (a >> 5) * GS + oR, ~(1u << (a & 31)));
       const int ax = a / N, ay = a - ax * N;
       pa = ay * N + (N - 1 - ax);
     }
     const int x = pa / N, y = pa - x * N;
-    lds_or(me + ((pa >> 5) << 9) + oR + player, 1u << (pa & 31));  // tb.cc:507-508 set peg
+    lds_or(me + (pa >> 5) * GS + oR + player, 1u << (pa & 31));  // tb.cc:507-508 set peg
 
     // ---- SetPegAndLinks (tb.cc:501-571), all 8 directions at once.  Six board
     //      columns x-3..x+2; per column one address, every plane by immediate
@@ -369,10 +379,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       const int c = x + ci;
       const bool ok = (unsigned)c < (unsigned)N;
       const int o = (ok ? c : 0) * N, sh = o & 31;
-      const uint32_t *const g = me + ((o >> 5) << 9);  // next word group: +512 dwords (in bounds: scalars/journal follow)
+      const uint32_t *const g = me + (o >> 5) * GS;  // next word group: +GS dwords (in bounds: scalars/journal follow)
 #ifdef TWX_COL_B128
-      const uint4 a0 = *reinterpret_cast<const uint4 *>(g), a1 = *reinterpret_cast<const uint4 *>(g + 256);
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(g + 512), b1 = *reinterpret_cast<const uint4 *>(g + 768);
+      const uint4 a0 = *reinterpret_cast<const uint4 *>(g), a1 = *reinterpret_cast<const uint4 *>(g + RS);
+      const uint4 b0 = *reinterpret_cast<const uint4 *>(g + GS), b1 = *reinterpret_cast<const uint4 *>(g + GS + RS);
       auto colv = [&](uint32_t lo, uint32_t hi) -> uint32_t {
         const uint32_t v = funnel(lo, hi, sh) & kColMask;
         return ok ? v : 0u;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       }
 #else
       auto col = [&](int off) -> uint32_t {
-        const uint32_t v = funnel(g[off], g[off + 512], sh) & kColMask;
+        const uint32_t v = funnel(g[off], g[off + GS], sh) & kColMask;
         return ok ? v : 0u;
       };
       if (ci >= -2) {
@@ -431,14 +441,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       constexpr uint32_t kDxPack = 0x10013443u, kDyPack = 0x43100134u;  // (offset + 2) per direction, 4 bits each
       const int tx = x + (int)((kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((kDyPack >> (4 * d)) & 15u) - 2;
       const int t = tx * N + ty;
-      uint32_t *const gt = me + ((t >> 5) << 9);
+      uint32_t *const gt = me + (t >> 5) * GS;
       uint32_t other = (gt[plane_off(2)] | gt[plane_off(3)] | gt[plane_off(4)] | gt[plane_off(5)]) >> (t & 31);
 #pragma unroll
       for (int e = 0; e < 4; e++) {  // links that END at t: stored at t - off[e]
         const int sx = tx - twx::kDX[e], sy = ty - twx::kDY[e];
         const bool valid = sx >= 0 && sy >= 0 && sy < N;
         const int sc2 = valid ? sx * N + sy : 0;
-        const uint32_t w = me[((sc2 >> 5) << 9) + plane_off(twx::kPlaneLink0 + e)];
+        const uint32_t w = me[(sc2 >> 5) * GS + plane_off(twx::kPlaneLink0 + e)];
         other |= valid ? (w >> (sc2 & 31)) : 0u;
       }
       if (!(other & 1u)) {
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     }
     pend = want;
     {  // tb.cc:532-533: one stored bit per physical link, at its west end
-      uint32_t *const g = me + ((pa >> 5) << 9);
+      uint32_t *const g = me + (pa >> 5) * GS;
       const uint32_t bit = 1u << (pa & 31);
 #pragma unroll
       for (int d = 0; d < 4; d++) lds_or(g + plane_off(twx::kPlaneLink0 + d), (linkm & (1u << d)) ? bit : 0u);
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
       for (int d = 4; d < 8; d++) {
         const bool on = (linkm & (1u << d)) != 0u;
         const int tc = on ? pa + twx::kDX[d] * N + twx::kDY[d] : pa;
-        lds_or(me + ((tc >> 5) << 9) + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
+        lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
       }
       lds_or(g + oS, gain_s ? bit : 0u);
       lds_or(g + oE, gain_e ? bit : 0u);
@@ -482,9 +492,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   *reinterpret_cast<uint4 *>(sc) = make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
   if (compact) {
     *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4 *>(jn + 256) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(jn + RS) = make_uint4(0u, 0u, 0u, 0u);
   } else {
-    jn[(jpos >> 2) * 256 + (jpos & 3)] = entry;
+    jn[(jpos >> 2) * RS + (jpos & 3)] = entry;
   }
   wave_sync();
 
@@ -494,24 +504,25 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   //      flag plane.  Frontier expansion: columns move by DPP wave shifts (1 VALU
   //      op each), rows by bit shifts; stop when no half found a new cell. ----
   uint64_t todo = __ballot(pend != 0u);
+  if (BPW == 32) todo &= 0xffffffffull;  // the upper half mirrors the lower one
   while (todo) {
     const int s0 = (int)__ffsll((unsigned long long)todo) - 1;
     todo &= todo - 1;
     const bool two = todo != 0ull;
     const int s1 = two ? (int)__ffsll((unsigned long long)todo) - 1 : s0;
     if (two) todo &= todo - 1;
-    const int half = lane >> 5, c = lane & 31;
-    const int src = half ? s1 : s0;
-    const int spa = half ? __builtin_amdgcn_readlane(pa, s1) : __builtin_amdgcn_readlane(pa, s0);
-    const uint32_t spend = (half && !two) ? 0u
-                           : (uint32_t)(half ? __builtin_amdgcn_readlane((int)pend, s1)
+    const int fh = lane >> 5, c = lane & 31;  // flood half: which of the two boards this lane works on
+    const int src = fh ? s1 : s0;
+    const int spa = fh ? __builtin_amdgcn_readlane(pa, s1) : __builtin_amdgcn_readlane(pa, s0);
+    const uint32_t spend = (fh && !two) ? 0u
+                           : (uint32_t)(fh ? __builtin_amdgcn_readlane((int)pend, s1)
                                              : __builtin_amdgcn_readlane((int)pend, s0));
     const int sx = spa / N, sy = spa - sx * N;
     const bool ok = c < N;
     const int o = (ok ? c : 0) * N, sh = o & 31, grp = o >> 5;
-    uint32_t *const g = lds + (src << 2) + (grp << 9);  // board `src`, this lane's column
+    uint32_t *const g = lds + (src << 2) + grp * GS;  // board `src`, this lane's column
     auto col = [&](int off) -> uint32_t {
-      const uint32_t v = funnel(g[off], g[off + 512], sh) & kColMask;
+      const uint32_t v = funnel(g[off], g[off + GS], sh) & kColMask;
       return ok ? v : 0u;
     };
     uint32_t lk[4];
@@ -546,10 +557,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         uint32_t dirty = 1u << grp;
         lds_or(g + off, add << sh);
         if (sh + N > 32) {
-          lds_or(g + off + 512, add >> (32 - sh));
+          lds_or(g + off + GS, add >> (32 - sh));
           dirty |= 2u << grp;
         }
-        lds_or(lds + (src << 2) + CS * 256 + 3, dirty);
+        lds_or(lds + (src << 2) + CS * RS + 3, dirty);
       }
       wave_sync();
       STAMP(14);  // flood: write-back
@@ -568,40 +579,46 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   // this batch's stores are issued, so that the wait at the top of the next iteration
   // does not also wait for those stores (loads and stores share one in-order counter).
 #pragma unroll
-  for (int c = 0; c < CHT; c++) asm volatile("" ::"v"(nxt[c]));
+  for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));
 
   STAMP(7);  // wait for the prefetched batch
   // ---- stream back ----
+  // (lane -> LDS row j*64+lane holds chunk chunk_of(j) of board bl: the fill's mapping)
   if (compact) {
 #pragma unroll
-    for (int c = 0; c < CHT; c++)
-      if (wr) state[(long)c * bpad + board] = lds4[c * kWave + lane];
+    for (int j = 0; j < NJ; j++)
+      if (wr && chunk_of(j) < CHT) state[(long)chunk_of(j) * bpad + board] = lds4[j * kWave + lane];
   } else {
     const int jc = CJ + (jpos >> 2);  // the journal chunk of slot jpos
-    if (wr) {
-      state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
-      state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+    if (BPW == 64) {
+      if (wr) {
+        state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
+        state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+      }
+    } else {  // one store: lower half the scalars chunk, upper half the journal chunk
+      const int c = half ? jc : CS;
+      if (wr) state[(long)c * bpad + board] = lds4[c * BPW + bl];
     }
     STAMP(9);  // fixed stores (scalars + journal chunk)
-    // flag chunks a flood fill changed: every dirty lane walks its own mask, all dirty
-    // lanes in parallel (per-lane chunk index), so the loop runs max-popcount times
-    uint32_t dd = (was_reset || !wr) ? 0u : dirty;
+    // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
+    // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
+    uint32_t dd = (was_reset || !wr || half) ? 0u : dirty;
     while (__ballot(dd != 0u)) {
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
         dd &= dd - 1;
-        state[(long)c * bpad + board] = lds4[c * kWave + lane];
+        state[(long)c * bpad + board] = lds4[c * BPW + bl];
       }
     }
     STAMP(10);  // dirty flag chunks
-    if (__ballot(was_reset)) {  // auto-reset lanes rewrite their whole board
+    if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
-      for (int c = 0; c < CHT; c++)
-        if (was_reset) state[(long)c * bpad + board] = lds4[c * kWave + lane];
+      for (int j = 0; j < NJ; j++)
+        if (was_reset && chunk_of(j) < CHT) state[(long)chunk_of(j) * bpad + board] = lds4[j * kWave + lane];
     }
   }
   STAMP(11);  // reset lanes / compaction
-  if (inb && !flush) {
+  if (inb && !flush && half == 0) {
     if (status) {
       uint8_t st = (uint8_t)(result | (swapped << 5));
       if (illegal) st |= TWX_ST_ILLEGAL;
@@ -616,6 +633,32 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
   }  // batch loop
   STAMP_FLUSH;
 }
+#undef plane_off
+
+// 64 boards per wave: 39 KiB LDS image, 4 waves per CU, all 512 registers of the SIMD
+template <int N, bool SUB>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel64(
+    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+  step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                        rsteps);
+}
+
+// 32 boards per wave: 20 KiB LDS image, 8 waves per CU (two per SIMD, 256 registers each).
+// Experiment (-DTWX_ENABLE_BPW32, TWX_BOARDS_PER_WAVE=32): bit-exact, but 15 % slower than
+// the 64-board kernel on MI355X (the duplicated per-board work doubles the issue demand
+// and the 256-register budget spills), so it is not built by default.
+#ifdef TWX_ENABLE_BPW32
+template <int N, bool SUB>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_kernel32(
+    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+  step_body<N, SUB, 32>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                        rsteps);
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // Layout-agnostic utility kernels (runtime N): reset / export / import / copy /
@@ -844,21 +887,29 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                       const int32_t *ids, long nsub, int rsteps, hipStream_t s) {
-  constexpr size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // 39 KiB at N=24: 4 waves per CU
-  const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
+                       const int32_t *ids, long nsub, int rsteps, int bpw, hipStream_t s) {
+  const long nbatch = ids ? (nsub + bpw - 1) / bpw : bpad / bpw;
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
-  if (ids)
-    hipLaunchKernelGGL((step_kernel<N, true>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
-                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps);
-  else
-    hipLaunchKernelGGL((step_kernel<N, false>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad,
-                       batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps);
+  const size_t rows = (bpw == 64) ? twx::Geo<N>::CHT : 2 * ((twx::Geo<N>::CHT + 1) / 2);
+  const size_t lds_bytes = rows * bpw * 16;  // 39 KiB (64 boards) or 20 KiB (32 boards) at N=24
+#define TWX_LAUNCH(K)                                                                                      \
+  hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
+                     actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps)
+  if (bpw == 64) {
+    if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
+  } else {
+#ifdef TWX_ENABLE_BPW32
+    if (ids) TWX_LAUNCH((step_kernel32<N, true>)); else TWX_LAUNCH((step_kernel32<N, false>));
+#else
+    return hipErrorInvalidConfiguration;
+#endif
+  }
+#undef TWX_LAUNCH
   return hipGetLastError();
 }
 
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, const int32_t *, long, int, hipStream_t);
+                              int, int, int, const int32_t *, long, int, int, hipStream_t);
 
 template <int N>
 struct StepTable {
@@ -899,6 +950,7 @@ struct twx_env {
   bool pingpong;
   uint64_t launches;
   int waves;  // persistent grid: resident waves = CUs x waves the LDS image admits per CU
+  int bpw;    // boards per wave: 64 or 32 (TWX_BOARDS_PER_WAVE)
 };
 
 namespace {
@@ -923,7 +975,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   if (flush || (!ids && e->jpos == e->period - 1)) flags |= kFlagCompact;
   if (e->pingpong && !ids && (e->launches & 1)) flags |= kFlagReverse;
   HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                           (uint32_t)e->first_id, flags, e->jpos, e->waves, ids, nsub, rsteps, s));
+                           (uint32_t)e->first_id, flags, e->jpos, e->waves, ids, nsub, rsteps, e->bpw, s));
   e->jpos = (flags & kFlagCompact) ? 0 : e->jpos + 1;
   e->launches++;
   return TWX_OK;
@@ -1005,9 +1057,16 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   {
     int cus = 0;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    const int lds_per_wave = e->d.CHT * kWave * 16;
+#ifdef TWX_ENABLE_BPW32
+    e->bpw = env_int("TWX_BOARDS_PER_WAVE", 64, 32, 64) >= 48 ? 64 : 32;
+#else
+    e->bpw = 64;
+#endif
+    const int rows = (e->bpw == 64) ? e->d.CHT : 2 * ((e->d.CHT + 1) / 2);
+    const int lds_per_wave = rows * e->bpw * 16;
     int per_cu = (160 * 1024) / lds_per_wave;  // MI355X: 160 KiB LDS per CU
-    if (per_cu > 8) per_cu = 8;
+    const int cap = (e->bpw == 64) ? 4 : 8;    // registers: 1 resp. 2 waves per SIMD
+    if (per_cu > cap) per_cu = cap;
     if (per_cu < 1) per_cu = 1;
     e->waves = (cus > 0 ? cus : 256) * env_int("TWX_WAVES_PER_CU", per_cu, 1, 32);
   }
