@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--prologue", type=int, default=700,
                     help="untimed setup steps that spread the boards over all game phases")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
     args = ap.parse_args()
@@ -149,10 +152,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     n, B = args.board_size, args.batch
     env = TwixtBatchEnv(n, B, local, first_board_id=shard_first_board(rank, B))
@@ -175,7 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
     if world > 1:
-        elapsed = max_over_ranks(elapsed, dist, "cuda")
+        elapsed = max_over_ranks(elapsed, dist, "cuda" if args.backend == "nccl" else "cpu")
 
     res, mc, _ = env.status()
     hist = torch.bincount(res.to(torch.int64), minlength=4).tolist()

@@ -99,11 +99,12 @@ def test_n24_intermediate_states(torch_mod):
     env.close()
 
 
-def test_external_actions_and_illegal(torch_mod):
-    """twx_step with caller-chosen actions, including illegal ones (tw.h:95-97)."""
+@pytest.mark.parametrize("n,batch,steps", [(8, 512, 75), (24, 96, 150), (5, 200, 26)])
+def test_external_actions_and_illegal(torch_mod, n, batch, steps):
+    """twx_step with caller-chosen actions, including illegal ones (tw.h:95-97) and forced
+    swaps (tb.cc:462-473), at the smallest, the default and the largest board."""
     import oracle_binding as ob
     torch = torch_mod
-    n, batch, steps = 8, 512, 75
     rng = np.random.default_rng(5)
     boards = [ob.Board(n) for _ in range(batch)]
     env = make_env(n, batch)
@@ -143,7 +144,7 @@ def test_external_actions_and_illegal(torch_mod):
         assert int(count[b]) == len(la)
         assert int(cp[b]) == bd.current_player()
         assert int(mc[b]) == bd.move_counter
-    assert int(sum(bd.s.swapped for bd in boards)) > 20
+    assert int(sum(bd.s.swapped for bd in boards)) > batch // 25
     env.close()
 
 
@@ -342,6 +343,10 @@ def test_subset_entry_points(torch_mod):
                 assert int(count[j]) == len(la) and int(mc[j]) == boards[b].move_counter
                 assert int(cp[j]) == boards[b].current_player()
                 assert np.array_equal(obs[j], boards[b].observation())
+    # ids outside [0, batch) are ignored rows: nothing moves, their status byte is untouched
+    st = torch.full((3,), 0xee, dtype=torch.uint8, device="cuda")
+    env.step(torch.tensor([5, 5, 5], dtype=torch.int32), status=st, ids=torch.tensor([-1, batch, 1 << 30], dtype=torch.int32))
+    assert st.cpu().tolist() == [0xee] * 3
     ref = np.stack([bd.planes() for bd in boards])
     compare_planes(env, ref, what="subset")
     env.close()

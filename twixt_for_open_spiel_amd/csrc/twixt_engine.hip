@@ -191,14 +191,16 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   auto batch_row = [&](long idx) -> long {
     return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * BPW + bl;
   };
-  auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : 0L) : j; };
+  // (an id outside [0, batch) makes its row a padding lane: nothing is stored, status untouched)
+  auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : -1L) : j; };
   auto batch_board = [&](long idx) -> long { return row_board(batch_row(idx)); };
   u32x4 nxt[NJ];
   const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
   u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
   long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
   {
-    const long b0 = batch_board(idx);
+    long b0 = batch_board(idx);
+    if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b0];
 #pragma unroll
@@ -207,8 +209,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   for (; idx < nbatch; idx += gridDim.x) {
   STAMP(0);  // loop overhead / previous stores issue
   const long row = batch_row(idx);
-  const long board = row_board(row);
-  const bool inb = ids ? (row < nsub) : (board < batch);
+  const long board_raw = row_board(row);
+  const bool inb = (unsigned long)board_raw < (unsigned long)batch;
+  const long board = (ids && !inb) ? 0L : board_raw;  // padding lanes of a subset load board 0
   const bool wr = !ids || inb;  // subset mode: padding lanes must not store
   const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
 #pragma unroll
@@ -217,7 +220,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // prefetch of the next batch, issued in three slices between the phases below so
   // that the wave never sits behind a 39-deep burst in its memory-issue queue (the
   // last iteration harmlessly re-reads its own batch)
-  const long b1 = batch_board((idx + gridDim.x < nbatch) ? idx + gridDim.x : idx);
+  long b1 = batch_board((idx + gridDim.x < nbatch) ? idx + gridDim.x : idx);
+  if (ids && (unsigned long)b1 >= (unsigned long)batch) b1 = 0;
   auto prefetch = [&](int c0, int c1) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -962,10 +966,14 @@ int env_int(const char *name, int dflt, int lo, int hi) {
   return x < lo ? lo : x > hi ? hi : x;
 }
 
+// a handle's work always goes to the handle's device, whatever the caller's current one is
+#define TWX_USE(e) HIP_TRY(hipSetDevice((e)->device))
+
 // one env step (or a flush) on every board, or on the `nsub` boards listed in `ids`;
 // maintains the journal position
 int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *status, uint32_t seed,
              int flags, const int32_t *ids, long nsub, hipStream_t s, int rsteps = 1) {
+  TWX_USE(e);
   const bool flush = (flags & kFlagFlush) != 0;
   if (ids && e->jpos == e->period - 1) {
     // a compaction must cover every board: do it as a flush, then step the subset on an
@@ -1116,6 +1124,7 @@ int64_t twx_batch(const twx_env *e) { return e ? e->d.batch : TWX_E_ARG; }
 
 int twx_reset(twx_env *e, void *stream) {
   if (!e) return fail(TWX_E_ARG, "twx_reset: env is NULL");
+  TWX_USE(e);
   e->jpos = 0;  // every journal is cleared below
   const long threads = (long)e->d.CHT * e->d.bpad;
   hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1127,6 +1136,7 @@ int twx_reset(twx_env *e, void *stream) {
 int twx_reset_boards(twx_env *e, const int32_t *ids, int64_t n, void *stream) {
   if (!e || !ids || n < 0) return fail(TWX_E_ARG, "twx_reset_boards: bad argument");
   if (n == 0) return TWX_OK;
+  TWX_USE(e);
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)e->d.CHT * n;
   hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1179,6 +1189,7 @@ int twx_legal_mask_boards(const twx_env *e, const int32_t *ids, int64_t n, uint3
   if (!e || !mask || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_legal_mask: bad argument");
   if (n == 0) return TWX_OK;
   hipStream_t s = (hipStream_t)stream;
+  TWX_USE(e);
   if (int rc = materialise(e, s)) return rc;
   if (count) HIP_TRY(hipMemsetAsync(count, 0, sizeof(int32_t) * n, s));
   const long threads = (long)e->d.W * n;
@@ -1198,6 +1209,7 @@ int twx_status_boards(const twx_env *e, const int32_t *ids, int64_t n, uint8_t *
   if (!e || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_status: bad argument");
   if (n == 0) return TWX_OK;
   // (scalars are written by every launch: no materialisation needed)
+  TWX_USE(e);
   hipLaunchKernelGGL(status_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, e->state, e->d,
                      ids, (long)n, result, move_counter, current_player);
   HIP_TRY(hipGetLastError());
@@ -1213,6 +1225,7 @@ int twx_status(const twx_env *e, uint8_t *result, int32_t *move_counter, int8_t 
 int twx_observation_boards(const twx_env *e, const int32_t *ids, int64_t n, float *out, void *stream) {
   if (!e || !out || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_observation: bad argument");
   if (n == 0) return TWX_OK;
+  TWX_USE(e);
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   hipLaunchKernelGGL(observation_kernel, dim3((unsigned)n), dim3(kWave), 0, (hipStream_t)stream, e->state, e->d,
                      ids, out);
@@ -1230,6 +1243,8 @@ int twx_copy_boards(twx_env *dst, const int32_t *dst_ids, const twx_env *src, co
   if (!dst || !src || !dst_ids || !src_ids || n < 0) return fail(TWX_E_ARG, "twx_copy_boards: bad argument");
   if (dst->d.n != src->d.n) return fail(TWX_E_ARG, "twx_copy_boards: board sizes differ");
   if (n == 0) return TWX_OK;
+  if (dst->device != src->device) return fail(TWX_E_ARG, "twx_copy_boards: handles live on different devices");
+  TWX_USE(dst);
   if (int rc = materialise(dst, (hipStream_t)stream)) return rc;
   if (int rc = materialise(src, (hipStream_t)stream)) return rc;
   const long threads = (long)dst->d.CH * n;
@@ -1242,6 +1257,7 @@ int twx_copy_boards(twx_env *dst, const int32_t *dst_ids, const twx_env *src, co
 int twx_export_state(const twx_env *e, const int32_t *ids, int64_t n, uint32_t *out, void *stream) {
   if (!e || !out || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_export_state: bad argument");
   if (n == 0) return TWX_OK;
+  TWX_USE(e);
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)e->d.SW * n;
   hipLaunchKernelGGL(export_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1253,6 +1269,7 @@ int twx_export_state(const twx_env *e, const int32_t *ids, int64_t n, uint32_t *
 int twx_import_state(twx_env *e, const int32_t *ids, int64_t n, const uint32_t *in, void *stream) {
   if (!e || !in || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_import_state: bad argument");
   if (n == 0) return TWX_OK;
+  TWX_USE(e);
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)e->d.CH * n;
   hipLaunchKernelGGL(import_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1264,6 +1281,7 @@ int twx_import_state(twx_env *e, const int32_t *ids, int64_t n, const uint32_t *
 int twx_export_cells(const twx_env *e, const int32_t *ids, int64_t n, uint8_t *out, void *stream) {
   if (!e || !out || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_export_cells: bad argument");
   if (n == 0) return TWX_OK;
+  TWX_USE(e);
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
   const long threads = (long)e->d.n * e->d.n * n;
   hipLaunchKernelGGL(cells_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
