@@ -380,3 +380,28 @@ def test_fused_rollout(torch_mod, n, batch):
             want = fresh
         assert np.array_equal(got[b, :-2], want[:-2]), "board %d" % b
     env.close()
+
+
+def test_committed_rollout_digests(torch_mod):
+    """HIP engine against the committed golden digests (tests/golden/rollout_digests.json)."""
+    import hashlib
+    with open(os.path.join(HERE, "golden", "rollout_digests.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        n, boards, steps = c["n"], c["boards"], c["steps"]
+        env = make_env(n, boards, first=c["first_board"])
+        acts = np.zeros((boards, steps), dtype=np.int32)
+        stat = np.zeros((boards, steps), dtype=np.uint8)
+        for t in range(steps):
+            a, s = env.step_random(c["seed"], c["auto_reset"])
+            acts[:, t] = a.cpu().numpy()
+            stat[:, t] = s.cpu().numpy()
+        planes = u32(env.export_state()).copy()
+        planes[:, -1] = 0
+        tag = "n=%d auto_reset=%s" % (n, c["auto_reset"])
+        assert hashlib.sha256(acts.tobytes()).hexdigest() == c["actions"], tag
+        assert hashlib.sha256(stat.tobytes()).hexdigest() == c["status"], tag
+        assert hashlib.sha256(planes.tobytes()).hexdigest() == c["planes"], tag
+        assert hashlib.sha256(env.export_cells().cpu().numpy().tobytes()).hexdigest() == c["cells"], tag
+        assert int((acts >= 0).sum()) == c["env_steps"]
+        env.close()

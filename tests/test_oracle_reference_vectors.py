@@ -151,3 +151,17 @@ def test_survey_kat(row, oracle):
     assert (k.moves, k.result, k.swapped, k.links) == (moves, result, swapped, links)
     if (n, seed) in KAT_DIGESTS:
         assert "%016x" % k.hist_fnv == KAT_DIGESTS[(n, seed)]
+
+
+def test_rollout_digests_reproducible():
+    """the committed golden digests of the policy rollouts are what the oracle produces now"""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_rollout_digests as g
+    with open(os.path.join(HERE, "golden", "rollout_digests.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 8
+    for c in cases:
+        d = g.digest(c["n"], c["boards"], c["steps"], c["seed"], c["first_board"], c["auto_reset"])
+        for k in ("actions", "status", "planes", "cells", "env_steps"):
+            assert d[k] == c[k], (c["n"], c["auto_reset"], k)

@@ -384,23 +384,6 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       const bool ok = (unsigned)c < (unsigned)N;
       const int o = (ok ? c : 0) * N, sh = o & 31;
       const uint32_t *const g = me + (o >> 5) * GS;  // next word group: +GS dwords (in bounds: scalars/journal follow)
-#ifdef TWX_COL_B128
-      const uint4 a0 = *reinterpret_cast<const uint4 *>(g), a1 = *reinterpret_cast<const uint4 *>(g + RS);
-      const uint4 b0 = *reinterpret_cast<const uint4 *>(g + GS), b1 = *reinterpret_cast<const uint4 *>(g + GS + RS);
-      auto colv = [&](uint32_t lo, uint32_t hi) -> uint32_t {
-        const uint32_t v = funnel(lo, hi, sh) & kColMask;
-        return ok ? v : 0u;
-      };
-      if (ci >= -2) {
-        wo[ci + 2] = ((colv(player ? a0.y : a0.x, player ? b0.y : b0.x) << 2) >> y) & 0x1fu;
-        ws[ci + 2] = ((colv(a1.z, b1.z) << 2) >> y) & 0x1fu;
-        we[ci + 2] = ((colv(a1.w, b1.w) << 2) >> y) & 0x1fu;
-      }
-      if (ci <= 1) {
-        win[ci + 3] = (((colv(a0.z, b0.z) << 3) >> y) & 0x7fu) | ((((colv(a0.w, b0.w) << 3) >> y) & 0x7fu) << 8) |
-                      ((((colv(a1.x, b1.x) << 3) >> y) & 0x7fu) << 16) | ((((colv(a1.y, b1.y) << 3) >> y) & 0x7fu) << 24);
-      }
-#else
       auto col = [&](int off) -> uint32_t {
         const uint32_t v = funnel(g[off], g[off + GS], sh) & kColMask;
         return ok ? v : 0u;
@@ -416,7 +399,6 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
         for (int e = 0; e < 4; e++) v |= (((col(plane_off(twx::kPlaneLink0 + e)) << 3) >> y) & 0x7fu) << (8 * e);
         win[ci + 3] = v;
       }
-#endif
     }
     uint32_t cand = 0, ts = 0, te = 0, blocked = 0;
 #pragma unroll
