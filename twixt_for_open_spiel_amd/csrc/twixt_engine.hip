@@ -631,6 +631,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
                         rsteps);
 }
 
+// small boards (LDS image <= 20 KiB, N <= 16): several waves per SIMD fit, so no
+// one-wave-per-SIMD register budget; the compiler keeps it within 256 registers
+template <int N, bool SUB>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_kernel64_small(
+    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+  step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                        rsteps);
+}
+
 // 32 boards per wave: 20 KiB LDS image, 8 waves per CU (two per SIMD, 256 registers each).
 // Experiment (-DTWX_ENABLE_BPW32, TWX_BOARDS_PER_WAVE=32): bit-exact, but 15 % slower than
 // the 64-board kernel on MI355X (the duplicated per-board work doubles the issue demand
@@ -882,7 +893,11 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
                      actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps)
   if (bpw == 64) {
-    if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
+    if constexpr (twx::Geo<N>::CHT <= 20) {
+      if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
+    } else {
+      if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
+    }
   } else {
 #ifdef TWX_ENABLE_BPW32
     if (ids) TWX_LAUNCH((step_kernel32<N, true>)); else TWX_LAUNCH((step_kernel32<N, false>));
@@ -894,30 +909,55 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
   return hipGetLastError();
 }
 
+// resident waves per CU of the whole-batch kernel for this N (LDS image + registers)
+template <int N>
+int step_occupancy(int bpw) {
+  const size_t rows = (bpw == 64) ? twx::Geo<N>::CHT : 2 * ((twx::Geo<N>::CHT + 1) / 2);
+  const size_t lds_bytes = rows * bpw * 16;
+  int blocks = 0;
+  hipError_t e;
+  if (bpw == 64) {
+    if constexpr (twx::Geo<N>::CHT <= 20)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64_small<N, false>, kWave, lds_bytes);
+    else
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64<N, false>, kWave, lds_bytes);
+  } else {
+#ifdef TWX_ENABLE_BPW32
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel32<N, false>, kWave, lds_bytes);
+#else
+    e = hipErrorInvalidConfiguration;
+#endif
+  }
+  return (e == hipSuccess && blocks > 0) ? blocks : 0;
+}
+
+typedef int (*occ_fn)(int);
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
                               int, int, int, const int32_t *, long, int, int, hipStream_t);
 
 template <int N>
 struct StepTable {
-  static void fill(step_fn *t) {
+  static void fill(step_fn *t, occ_fn *o) {
     t[N] = &launch_step<N>;
-    StepTable<N - 1>::fill(t);
+    o[N] = &step_occupancy<N>;
+    StepTable<N - 1>::fill(t, o);
   }
 };
 template <>
 struct StepTable<TWX_MIN_BOARD_SIZE - 1> {
-  static void fill(step_fn *) {}
+  static void fill(step_fn *, occ_fn *) {}
 };
 
-step_fn step_for(int n) {
-  static step_fn table[TWX_MAX_BOARD_SIZE + 1];
-  static bool init = false;
-  if (!init) {
-    StepTable<TWX_MAX_BOARD_SIZE>::fill(table);
-    init = true;
-  }
-  return table[n];
+struct StepTables {
+  step_fn step[TWX_MAX_BOARD_SIZE + 1];
+  occ_fn occ[TWX_MAX_BOARD_SIZE + 1];
+  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ); }
+};
+const StepTables &step_tables() {
+  static const StepTables t;  // thread-safe static init
+  return t;
 }
+step_fn step_for(int n) { return step_tables().step[n]; }
 
 inline unsigned blocks_for(long threads, int bs) { return (unsigned)((threads + bs - 1) / bs); }
 
@@ -1052,12 +1092,11 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
 #else
     e->bpw = 64;
 #endif
-    const int rows = (e->bpw == 64) ? e->d.CHT : 2 * ((e->d.CHT + 1) / 2);
-    const int lds_per_wave = rows * e->bpw * 16;
-    int per_cu = (160 * 1024) / lds_per_wave;  // MI355X: 160 KiB LDS per CU
-    const int cap = (e->bpw == 64) ? 4 : 8;    // registers: 1 resp. 2 waves per SIMD
-    if (per_cu > cap) per_cu = cap;
-    if (per_cu < 1) per_cu = 1;
+    // as many waves as are resident at once (LDS image and registers; 4 per CU at N=24,
+    // 8 at N=12, 12 at N=8): each walks its share of the batches
+    int per_cu = step_tables().occ[n](e->bpw);
+    if (per_cu < 1) per_cu = 4;
+    if (per_cu > 16) per_cu = 16;
     e->waves = (cus > 0 ? cus : 256) * env_int("TWX_WAVES_PER_CU", per_cu, 1, 32);
   }
   e->d.batch = batch;
