@@ -194,6 +194,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // (an id outside [0, batch) makes its row a padding lane: nothing is stored, status untouched)
   auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : -1L) : j; };
   auto batch_board = [&](long idx) -> long { return row_board(batch_row(idx)); };
+  STAMP_DECL;
   u32x4 nxt[NJ];
   const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
   u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
