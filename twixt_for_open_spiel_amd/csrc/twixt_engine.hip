@@ -1075,6 +1075,8 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     return fail(TWX_E_SIZE, "board_size out of range [5..24]: " + std::to_string(n));
   if (batch <= 0) return fail(TWX_E_ARG, "twx_create: batch must be positive");
   HIP_TRY(hipSetDevice(device));
+  int cus = 0;
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
   twx_env *e = new twx_env();
   e->d.n = n;
   e->d.W = twx::plane_words(n);
@@ -1086,8 +1088,6 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->pingpong = env_int("TWX_PINGPONG", 1, 0, 1) != 0;
   e->launches = 0;
   {
-    int cus = 0;
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 #ifdef TWX_ENABLE_BPW32
     e->bpw = env_int("TWX_BOARDS_PER_WAVE", 64, 32, 64) >= 48 ? 64 : 32;
 #else
@@ -1125,10 +1125,12 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     delete e;
     return fail(TWX_E_NOMEM, "twx_create: table upload failed");
   }
+  if (twx_reset(e, nullptr) != TWX_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+    const std::string why = g_err;
+    twx_destroy(e);
+    return fail(TWX_E_DEVICE, "twx_create: initial reset failed: " + why);
+  }
   *out = e;
-  int rc = twx_reset(e, nullptr);
-  if (rc != TWX_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(nullptr));
   return TWX_OK;
 }
 
