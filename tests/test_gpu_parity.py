@@ -299,11 +299,13 @@ def test_observation_sizes(torch_mod, n, batch, steps):
     env.close()
 
 
-def test_subset_entry_points(torch_mod):
+@pytest.mark.parametrize("period", [8, 1, 3])
+def test_subset_entry_points(torch_mod, period, monkeypatch):
     """twx_step_boards / twx_step_random_boards / *_boards queries: only the listed boards
     move (batched-leaf form), at every journal position, others stay bit-identical."""
     import oracle_binding as ob
     torch = torch_mod
+    monkeypatch.setenv("TWX_JOURNAL_PERIOD", str(period))
     n, batch, seed = 10, 500, 17
     env = make_env(n, batch, first=0)
     rng = np.random.default_rng(3)

@@ -998,12 +998,12 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
              int flags, const int32_t *ids, long nsub, hipStream_t s, int rsteps = 1) {
   TWX_USE(e);
   const bool flush = (flags & kFlagFlush) != 0;
-  if (ids && e->jpos == e->period - 1) {
+  if (ids && e->period > 1 && e->jpos == e->period - 1) {
     // a compaction must cover every board: do it as a flush, then step the subset on an
     // empty journal
     if (int rc = run_step(e, nullptr, nullptr, nullptr, 0u, kFlagFlush, nullptr, 0, s)) return rc;
   }
-  if (flush || (!ids && e->jpos == e->period - 1)) flags |= kFlagCompact;
+  if (flush || e->period == 1 || (!ids && e->jpos == e->period - 1)) flags |= kFlagCompact;
   if (e->pingpong && !ids && (e->launches & 1)) flags |= kFlagReverse;
   HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
                            (uint32_t)e->first_id, flags, e->jpos, e->waves, ids, nsub, rsteps, e->bpw, s));
