@@ -407,3 +407,34 @@ def test_committed_rollout_digests(torch_mod):
         assert hashlib.sha256(env.export_cells().cpu().numpy().tobytes()).hexdigest() == c["cells"], tag
         assert int((acts >= 0).sum()) == c["env_steps"]
         env.close()
+
+
+def test_random_configurations(torch_mod, monkeypatch):
+    """Property-style sweep: random (board size, batch, journal period, batch order, seed,
+    auto-reset, query interleaving); the final state and every status byte must equal the
+    oracle's."""
+    import oracle_binding as ob
+    rng = np.random.default_rng(2026)
+    for case in range(14):
+        n = int(rng.integers(5, 25))
+        batch = int(rng.integers(1, 400))
+        period = int(rng.integers(1, 9))
+        steps = int(rng.integers(1, 2 * n * n // 3))
+        seed = int(rng.integers(0, 1 << 31))
+        first = int(rng.integers(0, 1 << 20))
+        auto_reset = bool(rng.integers(0, 2))
+        monkeypatch.setenv("TWX_JOURNAL_PERIOD", str(period))
+        monkeypatch.setenv("TWX_PINGPONG", str(int(rng.integers(0, 2))))
+        env = make_env(n, batch, first=first)
+        stat = np.zeros((batch, steps), dtype=np.uint8)
+        for t in range(steps):
+            _, s = env.step_random(seed, auto_reset, want_actions=False)
+            stat[:, t] = s.cpu().numpy()
+            if rng.random() < 0.1:
+                env.legal_mask()      # forces a journal flush at a random position
+        ref = ob.rollout_batch(n, seed, first, batch, steps, auto_reset, want_trace=True, want_cells=True)
+        tag = "case %d: n=%d batch=%d period=%d steps=%d auto_reset=%s" % (case, n, batch, period, steps, auto_reset)
+        assert np.array_equal(stat, ref["status"]), tag
+        compare_planes(env, ref["planes"], what=tag)
+        assert np.array_equal(env.export_cells().cpu().numpy(), ref["cells"]), tag
+        env.close()

@@ -229,7 +229,11 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     for (int j = c0; j < c1; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b1];
     __builtin_amdgcn_sched_barrier(0);
   };
-  constexpr int kPf1 = NJ / 3, kPf2 = 2 * NJ / 3;
+#ifndef TWX_PF_A
+#define TWX_PF_A 4
+#define TWX_PF_B 8
+#endif
+  constexpr int kPf1 = NJ * TWX_PF_A / 12, kPf2 = NJ * TWX_PF_B / 12;  // slice boundaries
   prefetch(0, kPf1);
 
   STAMP(1);  // LDS fill + prefetch issue
@@ -356,7 +360,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
 
   STAMP(4);  // action select
-  if (rs == 0) prefetch(kPf2, CHT);
+  if (rs == 0) prefetch(kPf2, NJ);
   int pa = 0;          // cell the peg finally lands on
   uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
   uint32_t entry = 0;  // journal record of this move
