@@ -17,6 +17,14 @@
  *     Calls are asynchronous on that stream; the handle is re-entrant, there is
  *     no global mutable state (the reference's static BlockerMap, tb.h:150, has
  *     no counterpart).
+ *   - a handle is used from one host thread and one stream at a time (calls on it are
+ *     ordered by that stream).  Between compactions the board state is log-structured
+ *     (DESIGN.md): the step functions carry a host-side journal position as a launch
+ *     argument, so a sequence of steps must not be replayed from a captured hipGraph;
+ *     every other entry point first materialises the journal and is unaffected.
+ *   - tuning knobs read once by twx_create from the environment: TWX_JOURNAL_PERIOD
+ *     (1..8, default 8; 1 = rewrite the planes every step), TWX_PINGPONG (0/1, default 1:
+ *     alternate the batch order between launches), TWX_WAVES_PER_CU (default: occupancy).
  *   - action ids, players, results are the reference's: action = x*N + y
  *     (tb.cc:599-605), player 0 = red / 1 = blue (tc.h:52-53),
  *     result 0 open / 1 red win / 2 blue win / 3 draw (tb.h:48).
