@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {24: 1320, 12: 348, 8: 168}  # 2*S(N)+8
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0                     # same guide: measured float4-copy ceiling
 
 
 def algo_bytes(n):
@@ -193,6 +194,7 @@ def main():
         value = total_steps / elapsed
         ab = algo_bytes(n)
         achieved = ab * B / (kernel_ms * 1e-3) / 1e9
+        traffic = measured_traffic(n, B)
         out = {
             "metric": "env steps/sec at board_size=%d, batch=%d per GPU, random-action rollouts" % (n, B),
             "value": value,
@@ -212,7 +214,10 @@ def main():
                        "prologue_steps": args.prologue, "sharding": "contiguous board ids, no collectives",
                        "result_hist_rank0": hist},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n, B),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "moved_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                         "peak_measured_copy": HBM_COPY_GBS,
+                         "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                          "kernel": "step_kernel<%d>" % n, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": ab,
                          "note": "achieved = 1320 B x env steps / kernel time (SURVEY 8(d) model: full state "
