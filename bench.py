@@ -218,7 +218,7 @@ def main():
                          "moved_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                         "kernel": "step_kernel<%d>" % n, "kernel_ms": kernel_ms,
+                         "kernel": "step_kernel64<%d, false>" % n, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": ab,
                          "note": "achieved = 1320 B x env steps / kernel time (SURVEY 8(d) model: full state "
                                  "read + write per step).  The log-structured state rewrites the planes only "
