@@ -256,14 +256,16 @@ def test_full_size_sample(torch_mod):
     env.close()
 
 
-@pytest.mark.parametrize("period,pingpong", [(1, 0), (2, 1), (3, 0), (5, 1), (8, 0), (8, 1)])
-def test_journal_periods(torch_mod, period, pingpong, monkeypatch):
+@pytest.mark.parametrize("period,pingpong,rolling", [(1, 0, 1), (2, 1, 0), (3, 0, 1), (5, 1, 0), (8, 0, 0), (8, 1, 1),
+                                                     (4, 1, 1), (8, 0, 1)])
+def test_journal_periods(torch_mod, period, pingpong, rolling, monkeypatch):
     """The log-structured state must be invisible: any compaction period and block
     order gives the same trajectories, also when queries (which materialise the
     journal) are interleaved at odd places."""
     import oracle_binding as ob
     monkeypatch.setenv("TWX_JOURNAL_PERIOD", str(period))
     monkeypatch.setenv("TWX_PINGPONG", str(pingpong))
+    monkeypatch.setenv("TWX_ROLLING", str(rolling))
     n, batch, seed = 8, 640, 21
     env = make_env(n, batch, first=9)
     done = 0
@@ -425,6 +427,7 @@ def test_random_configurations(torch_mod, monkeypatch):
         auto_reset = bool(rng.integers(0, 2))
         monkeypatch.setenv("TWX_JOURNAL_PERIOD", str(period))
         monkeypatch.setenv("TWX_PINGPONG", str(int(rng.integers(0, 2))))
+        monkeypatch.setenv("TWX_ROLLING", str(int(rng.integers(0, 2))))
         env = make_env(n, batch, first=first)
         stat = np.zeros((batch, steps), dtype=np.uint8)
         for t in range(steps):
