@@ -73,3 +73,35 @@ def test_device_search_equals_oracle_search():
     bd, vd = BatchedMCTS(dev, leaves_per_batch=L, seed=9).search(pl, legal, 1024)
     bo, vo = BatchedMCTS(orc, leaves_per_batch=L, seed=9).search(pl, legal, 1024)
     assert vd == vo and bd == bo
+
+
+def _build_cpp_driver(out):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "twixt_for_open_spiel_amd")
+    from twixt_for_open_spiel_amd import build
+    build.build()
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
+                           "-I/opt/rocm/include", os.path.join(pkg, "spiel_adapter", "mcts_driver.cc"), "-o", out,
+                           "-L" + pkg, "-ltwixt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + pkg,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def test_cpp_driver_compiles(tmp_path):
+    _build_cpp_driver(str(tmp_path / "mcts_driver"))
+
+
+@pytest.mark.gpu
+def test_cpp_driver_plays_the_same_game(tmp_path):
+    """spiel_adapter/mcts_driver.cc (C++ host over the C ABI) and mcts.py make the same moves."""
+    import re
+    import subprocess
+    from twixt_for_open_spiel_amd.mcts import self_play
+    exe = _build_cpp_driver(str(tmp_path / "mcts_driver"))
+    out = subprocess.run([exe, "8", "640", "6", "128", "3"], capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    cpp_moves = [int(m) for m in re.findall(r"plays (\d+)", out.stdout.decode())]
+    hist, _, _ = self_play(8, max_simulations=640, leaves_per_batch=128, max_moves=6, seed=3)
+    assert cpp_moves == hist and len(hist) == 6
