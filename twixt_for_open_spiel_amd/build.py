@@ -5,7 +5,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "twixt_engine.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "twixt_geom.h"), os.path.join(ROOT, "include", "twixt_hip.h")]
+DEPS = [os.path.join(PKG, "csrc", f) for f in sorted(os.listdir(os.path.join(PKG, "csrc")))] + [
+    os.path.join(ROOT, "include", "twixt_hip.h")]
 LIB = os.path.join(PKG, "libtwixt_hip.so")
 
 

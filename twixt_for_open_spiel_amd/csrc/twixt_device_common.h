@@ -1,0 +1,94 @@
+// twixt_device_common.h -- wave size, launch flags, LDS / DPP / bit helpers, diagnostic stamps
+// Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
+#ifndef TWIXT_DEVICE_COMMON_H_
+#define TWIXT_DEVICE_COMMON_H_
+
+constexpr int kWave = 64;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte vector: stays in VGPRs
+
+// ---------------------------------------------------------------------------
+// Internal layout (HBM and LDS alike).  A board is CHT = 2W+3 chunks of 16 B:
+//   chunk 2i   = { red_i, blue_i, linkNNE_i, linkENE_i }      i = 0..W-1
+//   chunk 2i+1 = { linkESE_i, linkSSE_i, start_i, end_i }
+//   chunk 2W   = scalars { s0, s1, s2, s3 }
+//   chunk 2W+1, 2W+2 = redo journal, 8 x 32-bit records
+// i.e. the 8 planes are interleaved word by word: everything about the 32 cells
+// 32i..32i+31 sits in two adjacent chunks.  One address computation per cell /
+// column then reaches every plane through immediate offsets.
+// HBM: state[chunk][board] (uint4); LDS image of a wave: [chunk][lane] (uint4),
+// so chunk c of lane l starts at dword c*256 + l*4.
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {
+  __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_or_b32
+}
+__device__ __forceinline__ void lds_and(uint32_t *p, uint32_t v) {
+  __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_and_b32
+}
+
+// A workgroup is ONE wavefront and the LDS unit executes a wave's DS instructions in
+// issue order, so cross-lane hand-offs through LDS need no s_barrier: only the compiler
+// must not reorder the accesses.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// DPP wavefront shifts: lane i takes the value of lane i-1 / i+1, the end lane gets 0
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
+__device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int sh) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
+}
+
+// position of the k-th (0-based) set bit of a word that has more than k bits set
+__device__ __forceinline__ int select_bit(uint32_t t, int k) {
+  int pos = 0;
+  int c = __popc(t & 0xffffu);
+  if (k >= c) { k -= c; pos += 16; t >>= 16; }
+  c = __popc(t & 0xffu);
+  if (k >= c) { k -= c; pos += 8; t >>= 8; }
+  c = __popc(t & 0xfu);
+  if (k >= c) { k -= c; pos += 4; t >>= 4; }
+  c = __popc(t & 0x3u);
+  if (k >= c) { k -= c; pos += 2; t >>= 2; }
+  c = (int)(t & 1u);
+  if (k >= c) { pos += 1; }
+  return pos;
+}
+
+// In-kernel phase stamps (diagnostic build -DTWX_STAMPS only; never in the shipped
+// library): cycles per phase summed over all waves, read with twx_debug_stamps().
+#ifdef TWX_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[16] = {0}
+#define STAMP(i)                                                     \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+    const unsigned long long st_now = __builtin_amdgcn_s_memtime();  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+    st_acc[i] += st_now - st_prev;                                   \
+    st_prev = st_now;                                                \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#define STAMP_FLUSH                                                                      \
+  do {                                                                                   \
+    if (threadIdx.x == 0)                                                                \
+      for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_stamps[i_], st_acc[i_]);              \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush = 8, kFlagReverse = 16,
+              kFlagRolling = 32;  // + bits 8..11: journal period, bits 12..27: batch stride of a wave
+
+#endif  // TWIXT_DEVICE_COMMON_H_

@@ -1,0 +1,551 @@
+// twixt_step_kernel.h -- step_body<N,SUB,BPW> and its __global__ wrappers: the fused env step (hot path)
+// Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
+#ifndef TWIXT_STEP_KERNEL_H_
+#define TWIXT_STEP_KERNEL_H_
+
+// One launch = one env step on every board (or, with kFlagFlush, just the
+// materialisation of the redo journal).
+//
+// Log-structured state: between two compactions a launch does not
+// rewrite the planes; it appends one 32-bit record of the move to the board's
+// journal (slot `jpos`, the same for every board) and writes back only the
+// scalars chunk and that journal chunk.  The next launches replay slots
+// 0..jpos-1 on top of the planes they stream in.  Every `period`-th launch
+// (kFlagCompact) writes everything and clears the journal.  Lanes that
+// auto-reset write their whole board; lanes whose flood fill changed flag
+// words write those chunks.
+template <int N, bool SUB, int BPW>
+__device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, long batch,
+                                                     const int32_t *__restrict__ actions,
+                                                     int32_t *__restrict__ actions_out,
+                                                     uint8_t *__restrict__ status, uint32_t seed,
+                                                     uint32_t first_id, int flags, int jpos_arg,
+                                                     const int32_t *__restrict__ ids_arg, long nsub,
+                                                     int rsteps) {
+  using G = twx::Geo<N>;
+  const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
+  constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
+  // BPW boards per wave (64: one per lane; 32: both 32-lane halves run the same per-board
+  // logic on the same board -- every LDS update is an idempotent OR / AND / equal-value
+  // store -- while fills, prefetches and stores are split by half: the LDS image is half
+  // as big, so 8 waves fit a CU instead of 4).  RS = dwords per chunk row of the image.
+  static_assert(BPW == 64 || BPW == 32, "boards per wave");
+  constexpr int RS = BPW * 4, GS = 2 * RS;  // chunk-row / word-group stride in dwords
+  constexpr int NJ = (BPW == 64) ? CHT : (CHT + 1) / 2;  // 16-byte registers a lane prefetches
+#define plane_off(p) ((((p) >> 2) * RS) + ((p) & 3))
+  constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
+                oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
+  constexpr uint32_t kColMask = (1u << N) - 1u;
+  static_assert(CHT == 2 * W + 3 && W <= 32, "layout");
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
+
+  const int lane = threadIdx.x;
+  const int half = (BPW == 64) ? 0 : (lane >> 5);  // which chunk parity this lane moves
+  const int bl = lane & (BPW - 1);                 // board slot of this lane inside the batch
+  auto chunk_of = [&](int j) -> int { return (BPW == 64) ? j : 2 * j + half; };
+  const bool compact_all = (flags & kFlagCompact) != 0;
+  const bool flush = (flags & kFlagFlush) != 0;
+  const bool random = (flags & kFlagRandom) != 0;
+  // Rows: the boards this launch works on.  Whole batch: row j is board j (the allocation
+  // is padded to a multiple of 64, padded boards are real storage).  Subset (`ids`): row j
+  // is board ids[j]; lanes past nsub load board 0 and store nothing.
+  const long nbatch = ids ? (nsub + BPW - 1) / BPW : bpad / BPW;
+
+  // Persistent wave: walks batches idx = blockIdx.x, +gridDim.x, ...  While batch k is
+  // processed out of LDS, batch k+1 is already streaming into VGPRs (CHT x 16 B per
+  // lane), so HBM latency hides behind the integer work even at one wave per SIMD.
+  // kFlagReverse walks the batches backwards: the boards a launch touched last are the
+  // ones the next launch touches first (Infinity Cache reuse).
+  auto batch_row = [&](long idx) -> long {
+    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * BPW + bl;
+  };
+  // (an id outside [0, batch) makes its row a padding lane: nothing is stored, status untouched)
+  auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : -1L) : j; };
+  auto batch_board = [&](long idx) -> long { return row_board(batch_row(idx)); };
+  STAMP_DECL;
+  u32x4 nxt[NJ];
+  const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
+  u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
+  long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
+  {
+    long b0 = batch_board(idx);
+    if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b0];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
+  }
+  for (; idx < nbatch; idx += gridDim.x) {
+  STAMP(0);  // loop overhead / previous stores issue
+  // Rolling compaction (TWX_ROLLING=1, off by default): batch b is at journal position
+  // (phase + b) mod period, so every launch compacts one batch in `period` instead of every
+  // period-th launch compacting all of them.  Same traffic, spread evenly -- and 10 % slower
+  // on MI355X than the burst (0.173 vs 0.158 ms per launch): kept as a tested option only.
+  int jpos = jpos_arg;
+  bool compact = compact_all;
+  if (flags & kFlagRolling) {
+    const int period = (flags >> 8) & 15;
+    const long tb = (flags & kFlagReverse) ? (nbatch - 1 - idx) : idx;
+    // (+ tb / stride: a wave's successive batches tb, tb+stride, ... get different
+    // positions, so every wave compacts its share in every launch; `stride` is a per-handle
+    // constant, bits 12..27 of flags, so a batch's position is the same in every launch)
+    const long stride = (flags >> 12) & 0xffff;
+    jpos = (int)((jpos_arg + tb + tb / stride) % period);
+    compact = compact_all || (jpos == period - 1);
+  }
+  const long row = batch_row(idx);
+  const long board_raw = row_board(row);
+  const bool inb = (unsigned long)board_raw < (unsigned long)batch;
+  const long board = (ids && !inb) ? 0L : board_raw;  // padding lanes of a subset load board 0
+  const bool wr = !ids || inb;  // subset mode: padding lanes must not store
+  const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
+  wave_sync();
+  // prefetch of the next batch, issued in three slices between the phases below so
+  // that the wave never sits behind a 39-deep burst in its memory-issue queue (the
+  // last iteration harmlessly re-reads its own batch)
+  long b1 = batch_board((idx + gridDim.x < nbatch) ? idx + gridDim.x : idx);
+  if (ids && (unsigned long)b1 >= (unsigned long)batch) b1 = 0;
+  auto prefetch = [&](int c0, int c1) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = c0; j < c1; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b1];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#ifndef TWX_PF_A
+#define TWX_PF_A 4
+#define TWX_PF_B 8
+#endif
+  constexpr int kPf1 = NJ * TWX_PF_A / 12, kPf2 = NJ * TWX_PF_B / 12;  // slice boundaries
+  prefetch(0, kPf1);
+
+  STAMP(1);  // LDS fill + prefetch issue
+#ifdef TWX_SKELETON
+  prefetch(kPf1, NJ);
+  const bool was_reset = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
+  { uint32_t *const sk = lds + (bl << 2) + 2 * G::W * RS; sk[0] += 1u; }
+#else
+  uint32_t *const me = lds + (bl << 2);  // this board's slot inside every chunk row
+  // word group i (cells 32i..32i+31) of this board: me + i * GS [+ plane_off(p)]
+  uint32_t *const sc = me + CS * RS;     // scalars
+  uint32_t *const jn = me + CJ * RS;     // journal slot s at jn[(s >> 2) * RS + (s & 3)]
+
+  const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
+  uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
+  uint32_t result = sv.y & 0xffu, swapped = (sv.y >> 8) & 1u;
+  uint32_t episode = sv.z;
+  bool was_reset = false;
+
+  if (random && (flags & kFlagAutoReset) && result != 0u && inb) {
+    // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in place ----
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      *reinterpret_cast<uint4 *>(me + i * GS) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4 *>(me + i * GS + RS) =
+          make_uint4(0u, 0u, G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
+    }
+    *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(jn + RS) = make_uint4(0u, 0u, 0u, 0u);
+    counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
+    was_reset = true;
+  } else {
+    // ---- replay the redo journal: slots 0..jpos-1 in order, branch-free ORs ----
+#pragma unroll
+    for (int s = 0; s < twx::kJournalSlots - 1; s++) {
+      if (s < jpos) {  // wave-uniform
+        const uint32_t e = jn[(s >> 2) * RS + (s & 3)];
+        const int cell = (int)(e & 1023u);
+        const uint32_t bit = (e & twx::kJValid) ? (1u << (cell & 31)) : 0u;  // empty record: every OR is a no-op
+        uint32_t *const g = me + (cell >> 5) * GS;
+        if (e & (1u << 21)) lds_and(me + (move_one >> 5) * GS + oR, ~(1u << (move_one & 31)));  // swap: tb.cc:450-455
+        lds_or(g + oR + ((e >> 10) & 1u), bit);  // peg: red / blue words are adjacent
+#pragma unroll
+        for (int d = 0; d < 4; d++)  // links whose west end is this peg
+          lds_or(g + oL0 + plane_off(twx::kPlaneLink0 + d) - oL0, (e & (1u << (11 + d))) ? bit : 0u);
+#pragma unroll
+        for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
+          const bool on = (e & (1u << (11 + d))) != 0u;
+          const int tc = on ? cell + twx::kDX[d] * N + twx::kDY[d] : cell;
+          lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
+        }
+        lds_or(g + oS, (e & (1u << 19)) ? bit : 0u);
+        lds_or(g + oE, (e & (1u << 20)) ? bit : 0u);
+      }
+    }
+  }
+  wave_sync();
+
+  STAMP(2);  // reset / journal replay
+  int a = -1;
+  bool act = false, illegal = false;
+  uint32_t dirty = 0u;
+  // rsteps == 1: one env step.  rsteps > 1 (twx_random_rollout): up to rsteps moves per
+  // board with the state staying in LDS, until every board of the batch is terminal.
+  for (int rs = 0; rs < rsteps; rs++) {
+  if (rs == 0) prefetch(kPf1, kPf2);
+  const int player = (int)(counter & 1u);
+  const bool open = (result == 0u);
+
+  // ---- legal mask of the player to move (tw.h:86-90) and the
+  //      opponent's free-cell count (for the draw test of tb.cc:202-206) ----
+  uint32_t m[W];
+  int cnt_r = 0, cnt_b = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) {
+    const uint2 rb = *reinterpret_cast<const uint2 *>(me + i * GS);
+    const uint32_t occ = rb.x | rb.y;
+    uint32_t mr = G::tab.region[0][i] & ~occ;
+    uint32_t mb = G::tab.region[1][i] & ~occ;
+    cnt_r += __popc(mr);
+    cnt_b += __popc(mb);
+    if (counter == 1u) mb = G::tab.region[1][i] & ~rb.y;  // red's first peg stays legal for blue: the swap
+    m[i] = player ? mb : mr;
+  }
+  const int cnt_opp = player ? cnt_r : cnt_b;
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < W; i++) cnt += __popc(m[i]);
+
+  STAMP(3);  // legal mask + counts
+  // ---- choose / validate the action ----
+  a = -1;
+  act = inb && open && !flush;
+  illegal = false;
+  if (random) {
+    act = act && cnt > 0;
+    const uint32_t h = twx::policy_hash(seed, first_id + (uint32_t)board, episode, counter);
+    const int k = (int)__umulhi(h, (uint32_t)cnt);
+    int cum = 0, wsel = 0, base = 0;
+    uint32_t msel = m[0];
+#pragma unroll
+    for (int i = 0; i < W; i++) {  // last word whose prefix count is <= k
+      const bool ge = k >= cum;
+      wsel = ge ? i : wsel;
+      msel = ge ? m[i] : msel;
+      base = ge ? cum : base;
+      cum += __popc(m[i]);
+    }
+    a = wsel * 32 + select_bit(msel, k - base);
+    if (!act) a = -1;
+  } else if (!flush) {
+    a = a_ext;
+    bool legal = false;
+    if (a >= 0 && a < N * N) {
+      const int ax = a / N, ay = a - ax * N;
+      const bool inreg = player ? (ay >= 1 && ay <= N - 2) : (ax >= 1 && ax <= N - 2);
+      const uint32_t bit = 1u << (a & 31);
+      const uint2 rb = *reinterpret_cast<const uint2 *>(me + (a >> 5) * GS);
+      const bool occ = ((rb.y & bit) != 0u) || (counter != 1u && (rb.x & bit) != 0u);
+      legal = inreg && !occ;
+    }
+    illegal = inb && !(open && legal);  // tw.h:95-97 (terminal: LegalActions() is empty)
+    act = act && legal;
+  }
+
+  STAMP(4);  // action select
+  if (rs == 0) prefetch(kPf2, NJ);
+  int pa = 0;          // cell the peg finally lands on
+  uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
+  uint32_t entry = 0;  // journal record of this move
+  uint32_t fast_dirty = 0;  // flag chunk touched by the single-cell fill shortcut
+  if (act) {
+    // ---- Board::ApplyAction (tb.cc:457-499) ----
+    pa = a;
+    const bool swapnow = (counter == 1u) && ((uint32_t)a == move_one);
+    if (swapnow) {  // tb.cc:462-473: undo red's first peg, rotate 90 degrees
+      swapped = 1u;
+      lds_and(me + (a >> 5) * GS + oR, ~(1u << (a & 31)));
+      const int ax = a / N, ay = a - ax * N;
+      pa = ay * N + (N - 1 - ax);
+    }
+    const int x = pa / N, y = pa - x * N;
+    lds_or(me + (pa >> 5) * GS + oR + player, 1u << (pa & 31));  // tb.cc:507-508 set peg
+
+    // ---- SetPegAndLinks (tb.cc:501-571), all 8 directions at once.  Six board
+    //      columns x-3..x+2; per column one address, every plane by immediate
+    //      offset.  wo/ws/we: rows y-2..y+2 of own pegs / START / END (columns
+    //      x-2..x+2); win: rows y-3..y+3 of the 4 link planes (columns x-3..x+1) ----
+    uint32_t wo[5], ws[5], we[5], win[twx::kWinCols];
+#pragma unroll
+    for (int ci = -3; ci <= 2; ci++) {
+      const int c = x + ci;
+      const bool ok = (unsigned)c < (unsigned)N;
+      const int o = (ok ? c : 0) * N, sh = o & 31;
+      const uint32_t *const g = me + (o >> 5) * GS;  // next word group: +GS dwords (in bounds: scalars/journal follow)
+      auto col = [&](int off) -> uint32_t {
+        const uint32_t v = funnel(g[off], g[off + GS], sh) & kColMask;
+        return ok ? v : 0u;
+      };
+      if (ci >= -2) {
+        wo[ci + 2] = ((col(oR + player) << 2) >> y) & 0x1fu;
+        ws[ci + 2] = ((col(oS) << 2) >> y) & 0x1fu;
+        we[ci + 2] = ((col(oE) << 2) >> y) & 0x1fu;
+      }
+      if (ci <= 1) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v |= (((col(plane_off(twx::kPlaneLink0 + e)) << 3) >> y) & 0x7fu) << (8 * e);
+        win[ci + 3] = v;
+      }
+    }
+    uint32_t cand = 0, ts = 0, te = 0, blocked = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      const int ci = twx::kDX[d] + 2, rb = twx::kDY[d] + 2;
+      cand |= ((wo[ci] >> rb) & 1u) << d;  // same-colour peg a knight's move away (tb.cc:517)
+      ts |= ((ws[ci] >> rb) & 1u) << d;
+      te |= ((we[ci] >> rb) & 1u) << d;
+      uint32_t hit = 0;  // crossing test (tb.cc:519-527) as constant masks (twixt_geom.h)
+#pragma unroll
+      for (int i = 0; i < twx::kWinCols; i++) hit |= win[i] & twx::kCross.m[d][i];
+      blocked |= (hit != 0u ? 1u : 0u) << d;
+    }
+    const uint32_t linkm = cand & ~blocked;
+    // tb.cc:538-546: inherit START, else END, else remember a neutral neighbour
+    const uint32_t gain_s = linkm & ts, gain_e = linkm & ~ts & te, neutral = linkm & ~ts & ~te;
+    const bool p_s = ((ws[2] >> 2) & 1u) || gain_s;
+    const bool p_e = ((we[2] >> 2) & 1u) || gain_e;
+    uint32_t want = (linkm && neutral) ? ((p_s ? 1u : 0u) | (p_e ? 2u : 0u)) : 0u;  // tb.cc:558-570
+    // Half of all fills flag exactly one cell: the new peg's only unflagged neighbour is a
+    // peg without any other link.  Detect that here, on the pre-move planes, and set the
+    // flag directly; only the other fills go through the wave-cooperative pass below.
+    if (want && !(neutral & (neutral - 1u)) && (!(want & 1u) || (linkm & ~ts) == neutral) &&
+        (!(want & 2u) || (linkm & ~te) == neutral)) {
+      const int d = __ffs((int)neutral) - 1;
+      constexpr uint32_t kDxPack = 0x10013443u, kDyPack = 0x43100134u;  // (offset + 2) per direction, 4 bits each
+      const int tx = x + (int)((kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((kDyPack >> (4 * d)) & 15u) - 2;
+      const int t = tx * N + ty;
+      uint32_t *const gt = me + (t >> 5) * GS;
+      uint32_t other = (gt[plane_off(2)] | gt[plane_off(3)] | gt[plane_off(4)] | gt[plane_off(5)]) >> (t & 31);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {  // links that END at t: stored at t - off[e]
+        const int sx = tx - twx::kDX[e], sy = ty - twx::kDY[e];
+        const bool valid = sx >= 0 && sy >= 0 && sy < N;
+        const int sc2 = valid ? sx * N + sy : 0;
+        const uint32_t w = me[(sc2 >> 5) * GS + plane_off(twx::kPlaneLink0 + e)];
+        other |= valid ? (w >> (sc2 & 31)) : 0u;
+      }
+      if (!(other & 1u)) {
+        const uint32_t tbit = 1u << (t & 31);
+        lds_or(gt + oS, (want & 1u) ? tbit : 0u);
+        lds_or(gt + oE, (want & 2u) ? tbit : 0u);
+        fast_dirty = 1u << (t >> 5);
+        want = 0u;
+      }
+    }
+    pend = want;
+    {  // tb.cc:532-533: one stored bit per physical link, at its west end
+      uint32_t *const g = me + (pa >> 5) * GS;
+      const uint32_t bit = 1u << (pa & 31);
+#pragma unroll
+      for (int d = 0; d < 4; d++) lds_or(g + plane_off(twx::kPlaneLink0 + d), (linkm & (1u << d)) ? bit : 0u);
+#pragma unroll
+      for (int d = 4; d < 8; d++) {
+        const bool on = (linkm & (1u << d)) != 0u;
+        const int tc = on ? pa + twx::kDX[d] * N + twx::kDY[d] : pa;
+        lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
+      }
+      lds_or(g + oS, gain_s ? bit : 0u);
+      lds_or(g + oE, gain_e ? bit : 0u);
+      entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
+              (gain_s ? 1u << 19 : 0u) | (gain_e ? 1u << 20 : 0u) | (swapnow ? 1u << 21 : 0u);
+
+      if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
+      counter += 1u;
+      // ---- UpdateResult (tb.cc:192-207) ----
+      if (p_s && p_e) {
+        result = player ? 2u : 1u;
+      } else if (counter > 2u) {
+        const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
+        if (cnt_opp - (in_opp ? 1 : 0) == 0) result = 3u;
+      }
+    }
+  }
+  STAMP(5);  // apply: windows, crossing test, links, result
+  // s3 is used below as the board's dirty mask (bit i: flag words of group i changed)
+  *reinterpret_cast<uint4 *>(sc) = make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
+  if (compact) {
+    *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(jn + RS) = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    jn[(jpos >> 2) * RS + (jpos & 3)] = entry;
+  }
+  wave_sync();
+
+  // ---- ExploreLocalGraph (tb.cc:573-588), wave-cooperative, two boards per pass:
+  //      lanes 0..31 work on one board that needs a fill, lanes 32..63 on another;
+  //      lane c (within its half) holds column c of the four link planes and of the
+  //      flag plane.  Frontier expansion: columns move by DPP wave shifts (1 VALU
+  //      op each), rows by bit shifts; stop when no half found a new cell. ----
+  uint64_t todo = __ballot(pend != 0u);
+  if (BPW == 32) todo &= 0xffffffffull;  // the upper half mirrors the lower one
+  while (todo) {
+    const int s0 = (int)__ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const bool two = todo != 0ull;
+    const int s1 = two ? (int)__ffsll((unsigned long long)todo) - 1 : s0;
+    if (two) todo &= todo - 1;
+    const int fh = lane >> 5, c = lane & 31;  // flood half: which of the two boards this lane works on
+    const int src = fh ? s1 : s0;
+    const int spa = fh ? __builtin_amdgcn_readlane(pa, s1) : __builtin_amdgcn_readlane(pa, s0);
+    const uint32_t spend = (fh && !two) ? 0u
+                           : (uint32_t)(fh ? __builtin_amdgcn_readlane((int)pend, s1)
+                                             : __builtin_amdgcn_readlane((int)pend, s0));
+    const int sx = spa / N, sy = spa - sx * N;
+    const bool ok = c < N;
+    const int o = (ok ? c : 0) * N, sh = o & 31, grp = o >> 5;
+    uint32_t *const g = lds + (src << 2) + grp * GS;  // board `src`, this lane's column
+    auto col = [&](int off) -> uint32_t {
+      const uint32_t v = funnel(g[off], g[off + GS], sh) & kColMask;
+      return ok ? v : 0u;
+    };
+    uint32_t lk[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) lk[e] = col(plane_off(twx::kPlaneLink0 + e));
+    STAMP(12);  // flood: pass setup
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      const bool en = (spend >> f) & 1u;  // uniform per half
+      if (!__ballot(en)) continue;
+      const int off = f ? oE : oS;
+      const uint32_t flag0 = col(off);
+      uint32_t flag = flag0;
+      uint32_t front = (en && c == sx) ? (1u << sy) : 0u;
+      for (;;) {
+        // forward: a frontier cell with link e reaches (c+dx, y+dy).  dx = 1 for NNE/SSE,
+        // 2 for ENE/ESE: merge the row-shifted pairs, then shift lanes right by dx
+        const uint32_t a1 = ((front & lk[0]) << 2) | ((front & lk[3]) >> 2);
+        const uint32_t a2 = ((front & lk[1]) << 1) | ((front & lk[2]) >> 1);
+        uint32_t nb = wave_shr1(a1) | wave_shr1(wave_shr1(a2));
+        // backward: cell (c,y) whose link e ends in the frontier at (c+dx, y+dy)
+        const uint32_t f1 = wave_shl1(front), f2 = wave_shl1(f1);
+        nb |= ((f1 >> 2) & lk[0]) | ((f2 >> 1) & lk[1]) | ((f2 << 1) & lk[2]) | ((f1 << 2) & lk[3]);
+        const uint32_t fresh = ok ? (nb & ~flag & kColMask) : 0u;
+        flag |= fresh;
+        front = fresh;
+        if (__ballot(fresh != 0u) == 0ull) break;
+      }
+      STAMP(13);  // flood: iterations
+      const uint32_t add = flag & ~flag0;
+      if (ok && add) {
+        uint32_t dirty = 1u << grp;
+        lds_or(g + off, add << sh);
+        if (sh + N > 32) {
+          lds_or(g + off + GS, add >> (32 - sh));
+          dirty |= 2u << grp;
+        }
+        lds_or(lds + (src << 2) + CS * RS + 3, dirty);
+      }
+      wave_sync();
+      STAMP(14);  // flood: write-back
+    }
+  }
+  wave_sync();
+  STAMP(6);  // flood fill
+  dirty |= sc[3] | fast_dirty;
+  sc[3] = 0u;
+  wave_sync();
+  if (rs + 1 < rsteps && __ballot(inb && result == 0u) == 0ull) break;  // everyone finished
+  }  // rollout steps
+
+#endif  // TWX_SKELETON
+  // The prefetched batch has had the whole step to arrive: retire its loads HERE, before
+  // this batch's stores are issued, so that the wait at the top of the next iteration
+  // does not also wait for those stores (loads and stores share one in-order counter).
+#pragma unroll
+  for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));
+
+  STAMP(7);  // wait for the prefetched batch
+  // ---- stream back ----
+  // (lane -> LDS row j*64+lane holds chunk chunk_of(j) of board bl: the fill's mapping)
+  if (compact) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+      if (wr && chunk_of(j) < CHT) state[(long)chunk_of(j) * bpad + board] = lds4[j * kWave + lane];
+  } else {
+    const int jc = CJ + (jpos >> 2);  // the journal chunk of slot jpos
+    if (BPW == 64) {
+      if (wr) {
+        state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
+        state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+      }
+    } else {  // one store: lower half the scalars chunk, upper half the journal chunk
+      const int c = half ? jc : CS;
+      if (wr) state[(long)c * bpad + board] = lds4[c * BPW + bl];
+    }
+    STAMP(9);  // fixed stores (scalars + journal chunk)
+    // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
+    // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
+    uint32_t dd = (was_reset || !wr || half) ? 0u : dirty;
+    while (__ballot(dd != 0u)) {
+      if (dd) {
+        const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
+        dd &= dd - 1;
+        state[(long)c * bpad + board] = lds4[c * BPW + bl];
+      }
+    }
+    STAMP(10);  // dirty flag chunks
+    if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+        if (was_reset && chunk_of(j) < CHT) state[(long)chunk_of(j) * bpad + board] = lds4[j * kWave + lane];
+    }
+  }
+  STAMP(11);  // reset lanes / compaction
+  if (inb && !flush && half == 0) {
+    if (status) {
+      uint8_t st = (uint8_t)(result | (swapped << 5));
+      if (illegal) st |= TWX_ST_ILLEGAL;
+      if (was_reset) st |= TWX_ST_RESET;
+      if (random && !act) st |= TWX_ST_NOOP;
+      status[row] = st;
+    }
+    if (actions_out) actions_out[row] = a;
+  }
+  wave_sync();
+  STAMP(8);  // stream back + status
+  }  // batch loop
+  STAMP_FLUSH;
+}
+#undef plane_off
+
+// 64 boards per wave: 39 KiB LDS image, 4 waves per CU, all 512 registers of the SIMD
+template <int N, bool SUB>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel64(
+    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+  step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                        rsteps);
+}
+
+
+// small boards (LDS image <= 20 KiB, N <= 16): several waves per SIMD fit, so no
+// one-wave-per-SIMD register budget; the compiler keeps it within 256 registers
+template <int N, bool SUB>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_kernel64_small(
+    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+  step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                        rsteps);
+}
+
+// 32 boards per wave: 20 KiB LDS image, 8 waves per CU (two per SIMD, 256 registers each).
+// Experiment (-DTWX_ENABLE_BPW32, TWX_BOARDS_PER_WAVE=32): bit-exact, but 15 % slower than
+// the 64-board kernel on MI355X (the duplicated per-board work doubles the issue demand
+// and the 256-register budget spills), so it is not built by default.
+#ifdef TWX_ENABLE_BPW32
+template <int N, bool SUB>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_kernel32(
+    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
+    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+  step_body<N, SUB, 32>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                        rsteps);
+}
+#endif
+
+#endif  // TWIXT_STEP_KERNEL_H_
