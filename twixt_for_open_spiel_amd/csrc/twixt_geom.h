@@ -36,7 +36,10 @@ constexpr int state_chunks(int n) { return state_words(n) / 4; }  // 16-byte chu
 
 // Redo journal (DESIGN.md "Log-structured state"): kJournalSlots 32-bit move
 // records per board, stored in kJournalChunks extra chunks after the state.
-constexpr int kJournalSlots = 8;
+#ifndef TWX_JOURNAL_SLOTS
+#define TWX_JOURNAL_SLOTS 8
+#endif
+constexpr int kJournalSlots = TWX_JOURNAL_SLOTS;  // a multiple of 4 (whole 16-byte chunks)
 constexpr int kJournalChunks = kJournalSlots / 4;
 constexpr int total_chunks(int n) { return state_chunks(n) + kJournalChunks; }
 // record: bit31 valid | cell[9:0] | player[10] | link mask[18:11] | gain START[19] |

@@ -36,7 +36,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
                 oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
   constexpr uint32_t kColMask = (1u << N) - 1u;
-  static_assert(CHT == 2 * W + 3 && W <= 32, "layout");
+  static_assert(CHT == 2 * W + 1 + twx::kJournalChunks && W <= 32, "layout");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
 
@@ -146,8 +146,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       *reinterpret_cast<uint4 *>(me + i * GS + RS) =
           make_uint4(0u, 0u, G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
     }
-    *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4 *>(jn + RS) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < twx::kJournalChunks; k++) *reinterpret_cast<uint4 *>(jn + k * RS) = make_uint4(0u, 0u, 0u, 0u);
     counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
     was_reset = true;
   } else {
@@ -367,8 +367,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // s3 is used below as the board's dirty mask (bit i: flag words of group i changed)
   *reinterpret_cast<uint4 *>(sc) = make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
   if (compact) {
-    *reinterpret_cast<uint4 *>(jn) = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4 *>(jn + RS) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < twx::kJournalChunks; k++) *reinterpret_cast<uint4 *>(jn + k * RS) = make_uint4(0u, 0u, 0u, 0u);
   } else {
     jn[(jpos >> 2) * RS + (jpos & 3)] = entry;
   }
