@@ -24,7 +24,11 @@
  *     every other entry point first materialises the journal and is unaffected.
  *   - tuning knobs read once by twx_create from the environment: TWX_JOURNAL_PERIOD
  *     (1..8, default 8; 1 = rewrite the planes every step), TWX_PINGPONG (0/1, default 1:
- *     alternate the batch order between launches), TWX_WAVES_PER_CU (default: occupancy).
+ *     alternate the batch order between launches), TWX_WAVES_PER_CU (default: occupancy),
+ *     TWX_DYNAMIC (0/1, default 1: the last rounds of a launch are handed out by ticket
+ *     counters instead of a fixed wave -> batch map; like the journal position, the ticket
+ *     base is a launch argument kept by the host), TWX_DYNAMIC_STATIC (rounds in fixed
+ *     order before the tickets start; 0 = automatic).
  *   - action ids, players, results are the reference's: action = x*N + y
  *     (tb.cc:599-605), player 0 = red / 1 = blue (tc.h:52-53),
  *     result 0 open / 1 red win / 2 blue win / 3 draw (tb.h:48).

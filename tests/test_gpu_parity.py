@@ -386,6 +386,43 @@ def test_fused_rollout(torch_mod, n, batch):
     env.close()
 
 
+@pytest.mark.parametrize("dynamic,nstatic", [(0, 0), (1, 0), (1, 1), (1, 3), (1, 5), (1, 1000)])
+def test_dynamic_batch_order(torch_mod, dynamic, nstatic, monkeypatch):
+    """The ticket-drawn tail of a launch (TWX_DYNAMIC) only changes which wave works on which
+    64 boards: every board must still be stepped exactly once per launch.  One wave per CU and
+    ~100k boards give several rounds per wave, so static rounds, drawn rounds and a ragged
+    last round all occur; whole-batch steps (journalled), a subset step and a fused play-out."""
+    import oracle_binding as ob
+    torch = torch_mod
+    monkeypatch.setenv("TWX_WAVES_PER_CU", "1")
+    monkeypatch.setenv("TWX_DYNAMIC", str(dynamic))
+    monkeypatch.setenv("TWX_DYNAMIC_STATIC", str(nstatic))
+    n, batch, seed, first = 8, 100037, 31, 12345
+    env = make_env(n, batch, first=first)
+    steps = 45
+    stat = None
+    for t in range(steps):
+        _, stat = env.step_random(seed, True, want_actions=False)
+    ref = ob.rollout_batch(n, seed, first, batch, steps, True, want_trace=True)
+    assert np.array_equal(stat.cpu().numpy(), ref["status"][:, -1])
+    compare_planes(env, ref["planes"], what="dynamic=%d nstatic=%d" % (dynamic, nstatic))
+    # subset step on every other board: those boards advance by one move, the rest stay
+    ids = np.arange(1, batch, 2, dtype=np.int32)
+    env.step_random(seed, True, ids=torch.from_numpy(ids), want_actions=False, want_status=False)
+    got = u32(env.export_state())
+    ref1 = ob.rollout_batch(n, seed, first, batch, steps + 1, True)
+    sw = got.shape[1]
+    assert np.array_equal(got[1::2, :sw - 1], ref1["planes"][1::2, :sw - 1])
+    assert np.array_equal(got[0::2, :sw - 1], ref["planes"][0::2, :sw - 1])
+    # fused play-out of the whole batch from the initial position
+    env.reset()
+    st = env.random_rollout(seed).cpu().numpy()
+    ref2 = ob.rollout_batch(n, seed, first, batch, n * n - 3, False)
+    compare_planes(env, ref2["planes"], what="rollout dynamic=%d nstatic=%d" % (dynamic, nstatic))
+    assert (st & 3).all()
+    env.close()
+
+
 def test_committed_rollout_digests(torch_mod):
     """HIP engine against the committed golden digests (tests/golden/rollout_digests.json)."""
     import hashlib

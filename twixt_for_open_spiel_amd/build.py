@@ -21,7 +21,10 @@ def build(force=False, verbose=False):
     """Compile if the library is missing or older than its sources.  Returns the path."""
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # keep the ticket draw of the dynamic batch order a plain asynchronous atomic: the
+           # atomic optimizer would turn it into a wave reduction that waits for the result at once
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -89,6 +89,15 @@ __device__ unsigned long long g_stamps[16];
 #endif
 
 constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush = 8, kFlagReverse = 16,
-              kFlagRolling = 32;  // + bits 8..11: journal period, bits 12..27: batch stride of a wave
+              kFlagRolling = 32,  // + bits 8..11: journal period, bits 12..27: batch stride of a wave
+              kFlagDynamic = 64;  // batches after a wave's first are drawn from the ticket counters
+
+// dynamic batch order: one ticket counter per group of waves (blockIdx.x % kTicketGroups),
+// counters kTicketStride words apart; the bases travel as a kernel argument
+#ifndef TWX_TICKET_GROUPS
+#define TWX_TICKET_GROUPS 4  // measured: 1 and 2 contend on the counter, 4..16 are within 1 %
+#endif
+constexpr int kTicketGroups = TWX_TICKET_GROUPS, kTicketStride = 64;
+struct TicketBases { uint32_t b[kTicketGroups]; };
 
 #endif  // TWIXT_DEVICE_COMMON_H_

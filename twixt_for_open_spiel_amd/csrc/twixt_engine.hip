@@ -57,14 +57,15 @@ int fail(int code, const std::string &msg) {
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                       const int32_t *ids, long nsub, int rsteps, int bpw, hipStream_t s) {
+                       const int32_t *ids, long nsub, int rsteps, int bpw, uint32_t *ticket, TicketBases ticket_base,
+                       int nstatic, hipStream_t s) {
   const long nbatch = ids ? (nsub + bpw - 1) / bpw : bpad / bpw;
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
   const size_t rows = (bpw == 64) ? twx::Geo<N>::CHT : 2 * ((twx::Geo<N>::CHT + 1) / 2);
   const size_t lds_bytes = rows * bpw * 16;  // 39 KiB (64 boards) or 20 KiB (32 boards) at N=24
 #define TWX_LAUNCH(K)                                                                                      \
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
-                     actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps)
+                     actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, ticket, ticket_base, nstatic)
   if (bpw == 64) {
     if constexpr (twx::Geo<N>::CHT <= 20) {
       if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
@@ -139,7 +140,7 @@ typedef int (*wocc_fn)();
 
 typedef int (*occ_fn)(int);
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, const int32_t *, long, int, int, hipStream_t);
+                              int, int, int, const int32_t *, long, int, int, uint32_t *, TicketBases, int, hipStream_t);
 
 template <int N>
 struct StepTable {
@@ -192,6 +193,12 @@ struct twx_env {
   int init_off;    // word offset of the initial-position chunks inside `tables`
   bool window;     // use step_window_kernel for the non-compaction whole-batch launches
   int waves_win;   // its persistent grid
+  // dynamic batch order (TWX_DYNAMIC): device ticket counters (never reset) and the values
+  // they will have when the next launch starts
+  bool dynamic;
+  int dyn_static;  // batches every wave takes in static order before it draws tickets (0 = automatic)
+  uint32_t *ticket;
+  TicketBases ticket_base;
 };
 
 namespace {
@@ -235,8 +242,28 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
                                       (uint32_t)e->first_id, flags, jarg, e->waves_win,
                                       reinterpret_cast<const uint4 *>(e->tables + e->init_off), s));
   } else {
+    // dynamic tail: the groups need equal numbers of waves, and there must be batches beyond
+    // the first round; by default the last eighth of the rounds (at least two) is dynamic
+    const long nbatch = ids ? (nsub + e->bpw - 1) / e->bpw : e->d.bpad / e->bpw;
+    const long grid = nbatch < (long)e->waves ? nbatch : (long)e->waves;
+    const bool dyn = e->dynamic && grid % kTicketGroups == 0 && nbatch > grid;
+    const long rounds = nbatch / grid;  // whole rounds
+    long nstatic = e->dyn_static > 0 ? e->dyn_static : rounds - (rounds / 8 > 2 ? rounds / 8 : 2);
+    if (nstatic > rounds) nstatic = rounds;
+    if (nstatic < 1) nstatic = 1;
+    if (dyn) flags |= kFlagDynamic;
     HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                             (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->bpw, s));
+                             (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->bpw, e->ticket,
+                             e->ticket_base, (int)nstatic, s));
+    if (dyn) {
+      // group g: its dynamic batches (idx >= nstatic * grid, idx % groups == g) + two draws per
+      // wave that come back past the end (wraps with the counter)
+      const long first = nstatic * grid;
+      for (int g = 0; g < kTicketGroups; g++) {
+        const long nd = nbatch > first + g ? (nbatch - first - g + kTicketGroups - 1) / kTicketGroups : 0;
+        e->ticket_base.b[g] += (uint32_t)(nd + 2 * (grid / kTicketGroups));
+      }
+    }
   }
   if (flush) {
     e->journal_live = false;
@@ -331,6 +358,10 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->rolling = env_int("TWX_ROLLING", 0, 0, 1) != 0;  // measured 10 % slower than compacting all at once
   e->journal_live = false;
   e->launches = 0;
+  e->dynamic = env_int("TWX_DYNAMIC", 1, 0, 1) != 0;
+  e->dyn_static = env_int("TWX_DYNAMIC_STATIC", 0, 0, 1 << 20);  // 0 = automatic
+  e->ticket = nullptr;
+  e->ticket_base = TicketBases{};
   {
 #ifdef TWX_ENABLE_BPW32
     e->bpw = env_int("TWX_BOARDS_PER_WAVE", 64, 32, 64) >= 48 ? 64 : 32;
@@ -361,7 +392,8 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   // tables: region[2][W] (padded to a multiple of 4 words), then the initial position in
   // internal chunk order (CHT uint4)
   e->init_off = (2 * e->d.W + 3) & ~3;
-  std::vector<uint32_t> canon(2 * e->d.W + e->d.SW), tab(e->init_off + 4 * e->d.CHT, 0u);
+  // (+ zero words for the ticket counters of the dynamic batch order)
+  std::vector<uint32_t> canon(2 * e->d.W + e->d.SW), tab(e->init_off + 4 * e->d.CHT + kTicketGroups * kTicketStride, 0u);
   twx::fill_tables(n, canon.data(), canon.data() + 2 * e->d.W);
   for (int i = 0; i < 2 * e->d.W; i++) tab[i] = canon[i];
   for (int p = 0; p < twx::kNumPlanes; p++)
@@ -374,6 +406,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     delete e;
     return fail(TWX_E_NOMEM, "twx_create: table upload failed");
   }
+  e->ticket = e->tables + tab.size() - kTicketGroups * kTicketStride;
   if (twx_reset(e, nullptr) != TWX_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
     const std::string why = g_err;
     twx_destroy(e);

@@ -21,7 +21,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
                                                      uint8_t *__restrict__ status, uint32_t seed,
                                                      uint32_t first_id, int flags, int jpos_arg,
                                                      const int32_t *__restrict__ ids_arg, long nsub,
-                                                     int rsteps) {
+                                                     int rsteps, uint32_t *__restrict__ ticket,
+                                                     TicketBases tbase, int nstatic) {
   using G = twx::Geo<N>;
   const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
   constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
@@ -68,6 +69,35 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   const u32x4 *__restrict__ gstate = reinterpret_cast<const u32x4 *>(state);
   u32x4 *ldsv = reinterpret_cast<u32x4 *>(lds);
   long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
+  // Batch order.  Static: idx, idx + gridDim.x, ...  Dynamic (kFlagDynamic): every wave takes
+  // its first `nstatic` batches in that static order and then draws tickets from a device
+  // counter, so waves whose boards needed long flood fills take fewer batches and the launch
+  // does not end on its slowest wave (-4 % per launch at N=24, B=2^20).
+  //   * One counter for the whole chip is too slow: same-address device-scope atomics retire
+  //     at ~75 M/s on MI355X (0.229 ms per launch instead of 0.16 with a ticket per batch).
+  //     So only the tail of a launch is dynamic, and the waves form kTicketGroups groups by
+  //     blockIdx.x % kTicketGroups, each with its own counter: group g owns the dynamic
+  //     batches with idx % kTicketGroups == g.
+  //   * Counters are never reset.  Per launch, group g draws exactly (its dynamic batches +
+  //     2 per wave) tickets -- the two draws a wave has in flight when it runs past the end --
+  //     the host advances that group's base by as much, and ticket t is the group's dynamic
+  //     batch number t - base.
+  //   * A ticket is drawn two batches ahead of its use, together with the prefetch of the
+  //     batch before it, so its latency hides behind the step like the loads'.
+  const bool dyn = (flags & kFlagDynamic) != 0;
+  const int tgroup = blockIdx.x & (kTicketGroups - 1);
+  auto draw = [&]() -> uint32_t {
+    uint32_t t = 0u;
+    if (lane == 0)
+      t = __hip_atomic_fetch_add(ticket + tgroup * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  auto ticket_batch = [&](uint32_t tv) -> long {
+    const uint32_t k = __builtin_amdgcn_readfirstlane(tv) - tbase.b[tgroup];
+    return (long)nstatic * gridDim.x + (long)k * kTicketGroups + tgroup;
+  };
+  long round = 0;  // batches this wave has begun
+  uint32_t tv = (dyn && nstatic == 1) ? draw() : 0u;
   {
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
@@ -76,7 +106,10 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
 #pragma unroll
     for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
-  for (; idx < nbatch; idx += gridDim.x) {
+  long idx_next = (dyn && nstatic == 1) ? ticket_batch(tv) : idx + gridDim.x;
+  while (idx < nbatch) {
+  const bool drawn = dyn && round + 2 >= nstatic;  // is the batch after next a ticket?
+  if (drawn) tv = draw();
   STAMP(0);  // loop overhead / previous stores issue
   // Rolling compaction (TWX_ROLLING=1, off by default): batch b is at journal position
   // (phase + b) mod period, so every launch compacts one batch in `period` instead of every
@@ -106,7 +139,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // prefetch of the next batch, issued in three slices between the phases below so
   // that the wave never sits behind a 39-deep burst in its memory-issue queue (the
   // last iteration harmlessly re-reads its own batch)
-  long b1 = batch_board((idx + gridDim.x < nbatch) ? idx + gridDim.x : idx);
+  long b1 = batch_board((idx_next < nbatch) ? idx_next : idx);
   if (ids && (unsigned long)b1 >= (unsigned long)batch) b1 = 0;
   auto prefetch = [&](int c0, int c1) {
     __builtin_amdgcn_sched_barrier(0);
@@ -456,6 +489,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // does not also wait for those stores (loads and stores share one in-order counter).
 #pragma unroll
   for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));
+  // (the draw is older than the prefetch, so it has returned as well)
+  const long idx_after = drawn ? ticket_batch(tv) : (long)blockIdx.x + (round + 2) * gridDim.x;
 
   STAMP(7);  // wait for the prefetched batch
   // ---- stream back ----
@@ -506,6 +541,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
   wave_sync();
   STAMP(8);  // stream back + status
+  idx = idx_next;
+  idx_next = idx_after;
+  round++;
   }  // batch loop
   STAMP_FLUSH;
 }
@@ -516,9 +554,10 @@ template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel64(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
+    TicketBases tbase, int nstatic) {
   step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                        rsteps);
+                        rsteps, ticket, tbase, nstatic);
 }
 
 
@@ -528,9 +567,10 @@ template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_kernel64_small(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
+    TicketBases tbase, int nstatic) {
   step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                        rsteps);
+                        rsteps, ticket, tbase, nstatic);
 }
 
 // 32 boards per wave: 20 KiB LDS image, 8 waves per CU (two per SIMD, 256 registers each).
@@ -542,9 +582,10 @@ template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_kernel32(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps) {
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
+    TicketBases tbase, int nstatic) {
   step_body<N, SUB, 32>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                        rsteps);
+                        rsteps, ticket, tbase, nstatic);
 }
 #endif
 
