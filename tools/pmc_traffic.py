@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Reduce two rocprofv3 counter passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate runs of
+`bench.py --steps K --warmup 0 --no-cpu-baseline --no-rollout`) to the HBM bytes per launch
+and per env step of the step kernel: the `roofline.traffic` figure of bench.py.
+
+usage: pmc_traffic.py FETCH_DIR WRITE_DIR OUT_PREFIX [K=64] [N=24] [B=1048576]
+writes OUT_PREFIX_pmc_fetch.csv, OUT_PREFIX_pmc_write.csv (one row per timed launch) and
+OUT_PREFIX_traffic.json.  Corrections as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE
+reports half the bytes of a wide coalesced (16 B per lane) read stream and is doubled;
+WRITE_SIZE is exact for 16-byte-per-lane stores.  Both counters are in KB."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_dispatch(directory, counter, kernel_tag):
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *counter_collection.csv under " + directory)
+    acc = {}
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter or kernel_tag not in row["Kernel_Name"]:
+                    continue
+                d = int(row["Dispatch_Id"])
+                acc[d] = acc.get(d, 0.0) + float(row["Counter_Value"])  # summed over XCD rows
+    return sorted(acc.items())
+
+
+def main():
+    fetch_dir, write_dir, prefix = sys.argv[1:4]
+    k = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+    n = int(sys.argv[5]) if len(sys.argv) > 5 else 24
+    b = int(sys.argv[6]) if len(sys.argv) > 6 else 1 << 20
+    tag = "step_kernel64<%d, false>" % n
+    out = {}
+    for name, directory in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
+        rows = per_dispatch(directory, name, tag)[-k:]  # the timed launches come last
+        if len(rows) < k:
+            raise SystemExit("%s: only %d launches of %s" % (name, len(rows), tag))
+        with open("%s_pmc_%s.csv" % (prefix, name.split("_")[0].lower()), "w") as fh:
+            fh.write("Dispatch_Id,Counter_Name,Counter_Value_KB\n")
+            for d, v in rows:
+                fh.write("%d,%s,%.1f\n" % (d, name, v))
+        out[name] = sum(v for _, v in rows) / len(rows)
+    fetch = 2.0 * out["FETCH_SIZE"] * 1024.0
+    write = out["WRITE_SIZE"] * 1024.0
+    js = {
+        "FETCH_SIZE_KB_per_launch_mean": out["FETCH_SIZE"],
+        "WRITE_SIZE_KB_per_launch_mean": out["WRITE_SIZE"],
+        "kernel": tag,
+        "workload": "bench.py --steps %d --warmup 0 (N=%d, B=%d): last %d launches" % (k, n, b, k),
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
+                  "(MI355X_MICROARCH.md HBM section); FETCH_SIZE doubled: on gfx950 it reports 1/2 of the "
+                  "bytes of a wide coalesced (16 B/lane) read stream; WRITE_SIZE exact for 16-B-per-lane stores",
+        "fetch_bytes_corrected_per_launch": fetch,
+        "write_bytes_per_launch": write,
+        "hbm_bytes_per_launch": fetch + write,
+        "hbm_bytes_per_env_step": (fetch + write) / b,
+    }
+    with open(prefix + "_traffic.json", "w") as fh:
+        json.dump(js, fh, indent=1)
+    print(json.dumps(js))
+
+
+if __name__ == "__main__":
+    main()
