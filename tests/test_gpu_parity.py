@@ -256,6 +256,39 @@ def test_full_size_sample(torch_mod):
     env.close()
 
 
+def test_full_size_every_board(torch_mod):
+    """BASELINE config 3 at full size, every board: N=24, B=2^20, 300 auto-reset steps from
+    the initial position (3.1e8 env steps), the complete state of all 1,048,576 boards
+    compared bit-for-bit with the oracle (run on the host cores, 65,536 boards at a time)."""
+    import oracle_binding as ob
+    from bench import host_cores
+    torch = torch_mod
+    n, batch, steps, seed, first = 24, 1 << 20, 300, 3, 5 << 20
+    env = make_env(n, batch, first=first)
+    stat = None
+    for _ in range(steps):
+        _, stat = env.step_random(seed, True, want_actions=False)
+    torch.cuda.synchronize()
+    stat = stat.cpu().numpy()
+    threads = host_cores()
+    chunk = 1 << 16
+    total = 0
+    hist = np.zeros(4, dtype=np.int64)
+    for lo in range(0, batch, chunk):
+        ref = ob.rollout_batch(n, seed, first + lo, chunk, steps, True, threads=threads, want_trace=True)
+        ids = torch.arange(lo, lo + chunk, dtype=torch.int32)
+        got = u32(env.export_state(ids))
+        sw = got.shape[1]
+        assert np.array_equal(got[:, :sw - 1], ref["planes"][:, :sw - 1]), "boards %d..%d" % (lo, lo + chunk)
+        assert np.array_equal(stat[lo:lo + chunk], ref["status"][:, -1]), "status %d..%d" % (lo, lo + chunk)
+        total += ref["steps"]
+        hist += np.bincount(ref["planes"][:, sw - 3] & 3, minlength=4)
+    res, _, _ = env.status()
+    assert np.array_equal(torch.bincount(res.to(torch.int64), minlength=4).cpu().numpy(), hist)
+    assert total > 0.95 * batch * steps   # nearly every launch steps every board (auto-reset)
+    env.close()
+
+
 @pytest.mark.parametrize("period,pingpong,rolling", [(1, 0, 1), (2, 1, 0), (3, 0, 1), (5, 1, 0), (8, 0, 0), (8, 1, 1),
                                                      (4, 1, 1), (8, 0, 1)])
 def test_journal_periods(torch_mod, period, pingpong, rolling, monkeypatch):
