@@ -5,17 +5,20 @@
 // the same games; the Python one is the readable reference, this one removes the
 // interpreter from the loop.
 //
-//   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include mcts_driver.cc \
-//       -Ltwixt_for_open_spiel_amd -ltwixt_hip -L/opt/rocm/lib -lamdhip64 -o mcts_driver
+//   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include mcts_driver.cc
+//     -Ltwixt_for_open_spiel_amd -ltwixt_hip -L/opt/rocm/lib -lamdhip64 -o mcts_driver
 //   ./mcts_driver [board_size=12] [max_simulations=20000] [moves=0 (whole game)] [leaves=2048] [seed=1]
 #include <hip/hip_runtime_api.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <map>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "twixt_hip.h"
@@ -23,20 +26,46 @@
 #define TWX(x) do { if ((x) != TWX_OK) { std::fprintf(stderr, "%s: %s\n", #x, twx_last_error()); std::exit(1); } } while (0)
 #define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
+// A node keeps its children's statistics in its own arrays (cn / cw, indexed like `legal`),
+// so that the UCT scan of a node reads contiguous memory; a child reaches its own counters
+// through (parent, slot).  Children are created in ascending action order -- an uncreated
+// child scores 1e9 in mcts.py and the first maximum wins -- so `created` children are
+// always the prefix legal[0..created) and the next new child is found without a scan.
 struct Node {
   Node *parent;
+  int slot;           // index in the parent's arrays (-1 at the root)
   int action, mover;  // mover: who played `action` (-1 at the root)
   int player = -1;    // to move here, known once expanded
   bool expanded = false;
   int terminal = 0;   // result if the game is over here
-  long n = 0;
-  double w = 0.0;     // summed return for `mover`
+  double root_n = 0.0, root_w = 0.0;  // the root's own counters
   std::vector<int> legal;
-  std::map<int, std::unique_ptr<Node>> children;
-  Node(Node *p, int a, int m) : parent(p), action(a), mover(m) {}
+  std::vector<double> cn, cw;  // per child: visits, summed return for this node's player
+  std::vector<std::unique_ptr<Node>> child;
+  size_t created = 0;
+  Node(Node *p, int sl, int a, int m) : parent(p), slot(sl), action(a), mover(m) {}
+  double &n() { return parent ? parent->cn[slot] : root_n; }
+  double &w() { return parent ? parent->cw[slot] : root_w; }
+  void Expand(std::vector<int> la, int to_move) {
+    expanded = true;
+    legal = std::move(la);
+    player = to_move;
+    cn.assign(legal.size(), 0.0);
+    cw.assign(legal.size(), 0.0);
+    child.resize(legal.size());
+  }
 };
 
 struct Leaf { int result, player; std::vector<int> legal; int final_result; };
+
+// wall-clock shares of a run (printed at the end): tree work on the host vs device round trips
+static double g_t[5];  // select, path replay, leaf query, play-outs, backup
+struct Timer {
+  int slot;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit Timer(int s) : slot(s) {}
+  ~Timer() { g_t[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // slots 0..L-1 are scratch leaves, slot L is the root (mcts.py: DeviceEvaluator)
 class Device {
@@ -75,6 +104,7 @@ class Device {
   }
   std::vector<Leaf> Evaluate(const std::vector<std::vector<int>> &paths, uint32_t seed) {
     const int k = (int)paths.size();
+    std::unique_ptr<Timer> tm(new Timer(1));
     TWX(twx_copy_boards(env_, d_iota_, env_, d_src_, k, nullptr));  // root -> slots 0..k-1
     size_t depth = 0;
     for (auto &p : paths) depth = std::max(depth, p.size());
@@ -88,8 +118,14 @@ class Device {
       HIP(hipMemcpy(d_act_, acts.data(), 4 * acts.size(), hipMemcpyHostToDevice));
       TWX(twx_step_boards(env_, d_ids_, (int64_t)rows.size(), d_act_, nullptr, nullptr));
     }
-    std::vector<Leaf> out = Query(d_iota_, k);
+    tm.reset(new Timer(2));
+    // status and legal masks of the leaves, then the play-outs, all queued before the first
+    // read-back (the play-outs do not touch the query buffers)
+    TWX(twx_status_boards(env_, d_iota_, k, d_res_, nullptr, d_cp_, nullptr));
+    TWX(twx_legal_mask_boards(env_, d_iota_, k, d_mask_, nullptr, nullptr));
     TWX(twx_random_rollout(env_, d_iota_, k, seed, n_ * n_ - 3, d_st_, nullptr));  // terminal leaves stay
+    std::vector<Leaf> out = ReadQuery(k);
+    tm.reset(new Timer(3));
     std::vector<uint8_t> st(k);
     HIP(hipMemcpy(st.data(), d_st_, k, hipMemcpyDeviceToHost));
     for (int i = 0; i < k; i++) out[i].final_result = st[i] & TWX_ST_RESULT_MASK;
@@ -105,6 +141,9 @@ class Device {
   std::vector<Leaf> Query(const int32_t *ids, int k) {
     TWX(twx_status_boards(env_, ids, k, d_res_, nullptr, d_cp_, nullptr));
     TWX(twx_legal_mask_boards(env_, ids, k, d_mask_, nullptr, nullptr));
+    return ReadQuery(k);
+  }
+  std::vector<Leaf> ReadQuery(int k) {
     std::vector<uint8_t> res(k);
     std::vector<int8_t> cp(k);
     std::vector<uint32_t> mask((size_t)W_ * k);
@@ -116,9 +155,11 @@ class Device {
       out[i].result = res[i];
       out[i].player = cp[i];
       out[i].final_result = res[i];
-      if (res[i] == 0)
-        for (int a = 0; a < n_ * n_; a++)
-          if ((mask[(size_t)i * W_ + (a >> 5)] >> (a & 31)) & 1u) out[i].legal.push_back(a);
+      if (res[i] == 0) {
+        out[i].legal.reserve(n_ * (n_ - 2));
+        for (int w = 0; w < W_; w++)  // ascending action ids: LegalActions() order (tw.h:86-90)
+          for (uint32_t m = mask[(size_t)i * W_ + w]; m; m &= m - 1) out[i].legal.push_back(32 * w + __builtin_ctz(m));
+      }
     }
     return out;
   }
@@ -135,65 +176,104 @@ static void Returns(int result, double r[2]) {  // twixt.h:50-63
   r[1] = -r[0];
 }
 
+// UCT values of all children of a node: val[i] = cw[i]/cn[i] + c*sqrt(logn/cn[i]).  IEEE
+// division, square root, multiplication and addition round the same in scalar and vector
+// form and nothing is contracted into an FMA (the AVX2 target has none), so the vector
+// path returns the bits mcts.py computes.
+static void UctValuesScalar(const double *cn, const double *cw, double *val, size_t i, size_t m, double logn,
+                            double c) {
+  for (; i < m; i++) val[i] = cw[i] / cn[i] + c * std::sqrt(logn / cn[i]);
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void UctValuesAvx2(const double *cn, const double *cw, double *val, size_t m,
+                                                          double logn, double c) {
+  const __m256d vl = _mm256_set1_pd(logn), vc = _mm256_set1_pd(c);
+  size_t i = 0;
+  for (; i + 4 <= m; i += 4) {
+    const __m256d n = _mm256_loadu_pd(cn + i), w = _mm256_loadu_pd(cw + i);
+    const __m256d u = _mm256_mul_pd(vc, _mm256_sqrt_pd(_mm256_div_pd(vl, n)));
+    _mm256_storeu_pd(val + i, _mm256_add_pd(_mm256_div_pd(w, n), u));
+  }
+  UctValuesScalar(cn, cw, val, i, m, logn, c);
+}
+#endif
+static void UctValues(const double *cn, const double *cw, double *val, size_t m, double logn, double c) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return UctValuesAvx2(cn, cw, val, m, logn, c);
+#endif
+  UctValuesScalar(cn, cw, val, 0, m, logn, c);
+}
+
 class Mcts {
  public:
   Mcts(Device *dev, int leaves, uint32_t seed, double c = 2.0) : dev_(dev), L_(leaves), seed_(seed), c_(c) {}
   int Search(int root_player, const std::vector<int> &root_legal, long max_sims, long *best_visits) {
-    Node root(nullptr, -1, -1);
-    root.expanded = true;
-    root.legal = root_legal;
-    root.player = root_player;
+    Node root(nullptr, -1, -1, -1);
+    root.Expand(root_legal, root_player);
     for (long done = 0; done < max_sims;) {
       const long k = std::min<long>(L_, max_sims - done);
       std::vector<Node *> leaves(k);
       std::vector<std::vector<int>> paths(k);
-      for (long i = 0; i < k; i++) leaves[i] = Select(&root, &paths[i]);
-      const std::vector<Leaf> out = dev_->Evaluate(paths, seed_ + (uint32_t)batches_++);
+      {
+        Timer tm(0);
+        for (long i = 0; i < k; i++) leaves[i] = Select(&root, &paths[i]);
+      }
+      std::vector<Leaf> out = dev_->Evaluate(paths, seed_ + (uint32_t)batches_++);
+      Timer tm(4);
       for (long i = 0; i < k; i++) {
         Node *leaf = leaves[i];
         if (out[i].result != 0) leaf->terminal = out[i].result;
-        else if (!leaf->expanded) { leaf->expanded = true; leaf->legal = out[i].legal; leaf->player = out[i].player; }
+        else if (!leaf->expanded) leaf->Expand(std::move(out[i].legal), out[i].player);
         Backup(leaf, out[i].result != 0 ? out[i].result : out[i].final_result);
       }
       done += k;
     }
     int best = -1;
     long bv = -1;
-    for (auto &kv : root.children)  // ascending action id; first maximum wins
-      if (kv.second->n > bv) { bv = kv.second->n; best = kv.first; }
+    for (size_t i = 0; i < root.created; i++)  // ascending action id; first maximum wins
+      if ((long)root.cn[i] > bv) { bv = (long)root.cn[i]; best = root.legal[i]; }
     *best_visits = bv;
     return best;
   }
 
  private:
+  // mcts.py BatchedMCTS._select: same order, same double arithmetic (w/n + c*sqrt(log N / n)).
+  // The values are computed first (vectorised, UctValues), the arg-max scan follows.
+  size_t BestChild(Node *node) {
+    const size_t m = node->legal.size();
+    if (node->created < m) return node->created;  // the first uncreated child scores 1e9
+    const double logn = std::log(node->n());
+    val_.resize(m);
+    double *val = val_.data();
+    UctValues(node->cn.data(), node->cw.data(), val, m, logn, c_);
+    size_t best = 0;
+    double best_v = -1e30;
+    for (size_t i = 0; i < m; i++)
+      if (val[i] > best_v) { best = i; best_v = val[i]; }
+    return best;
+  }
   Node *Select(Node *root, std::vector<int> *path) {
     Node *node = root;
     for (;;) {
-      node->n += 1;
-      node->w -= 1.0;  // virtual loss
+      node->n() += 1.0;
+      node->w() -= 1.0;  // virtual loss
       if (node->terminal != 0 || !node->expanded) return node;
-      int best = -1;
-      double best_v = -1e30;
-      const double logn = std::log((double)node->n);
-      for (int a : node->legal) {
-        auto it = node->children.find(a);
-        double v;
-        if (it == node->children.end() || it->second->n == 0) v = 1e9;
-        else v = it->second->w / (double)it->second->n + c_ * std::sqrt(logn / (double)it->second->n);
-        if (v > best_v) { best = a; best_v = v; }
+      const size_t i = BestChild(node);
+      if (!node->child[i]) {
+        node->child[i].reset(new Node(node, (int)i, node->legal[i], node->player));
+        node->created = i + 1;
       }
-      auto &ch = node->children[best];
-      if (!ch) ch.reset(new Node(node, best, node->player));
-      node = ch.get();
-      path->push_back(best);
+      node = node->child[i].get();
+      path->push_back(node->action);
     }
   }
   void Backup(Node *leaf, int result) {
     double r[2];
     Returns(result, r);
     for (Node *node = leaf; node; node = node->parent) {
-      node->w += 1.0;
-      if (node->mover >= 0) node->w += r[node->mover];
+      node->w() += 1.0;
+      if (node->mover >= 0) node->w() += r[node->mover];
     }
   }
   Device *dev_;
@@ -201,6 +281,7 @@ class Mcts {
   uint32_t seed_;
   double c_;
   long batches_ = 0;
+  std::vector<double> val_;
 };
 
 int main(int argc, char **argv) {
@@ -229,5 +310,7 @@ int main(int argc, char **argv) {
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("result %d after %d moves; %ld simulations in %.2f s = %.0f simulations/s\n", result, moves, total, dt,
               total / dt);
+  std::printf("time: select %.2f s, path replay %.2f s, leaf query %.2f s, play-outs %.2f s, backup %.2f s\n", g_t[0],
+              g_t[1], g_t[2], g_t[3], g_t[4]);
   return 0;
 }
