@@ -111,7 +111,8 @@ def fused_rollout(env, seed):
     steps = int(mc.to(torch.int64).sum())
     return {"value": steps / (ms * 1e-3), "unit": "env steps/s", "launch_ms": ms, "env_steps": steps,
             "playouts_per_s": env.batch / (ms * 1e-3),
-            "model": "whole random play-outs in one launch; HBM traffic 2*624 B per play-out"}
+            "model": "whole random play-outs in one launch; HBM traffic 2*%d B per play-out (state read + "
+                     "written once)" % (16 * (2 * ((env.board_size ** 2 + 31) // 32) + 2))}
 
 
 def shard_first_board(rank, batch_per_gpu):
@@ -218,12 +219,16 @@ def main():
                          "moved_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                         "kernel": "step_kernel64<%d, false>" % n, "kernel_ms": kernel_ms,
+                         "kernel": ("step_kernel64_small<%d, false>" if 2 * ((n * n + 31) // 32) + 3 <= 20
+                                    else "step_kernel64<%d, false>") % n,
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": ab,
-                         "note": "achieved = 1320 B x env steps / kernel time (SURVEY 8(d) model: full state "
+                         "note": "achieved = %d B x env steps / kernel time (SURVEY 8(d) model: full state "
                                  "read + write per step).  The log-structured state rewrites the planes only "
-                                 "every 8th launch, so the kernel moves ~760 B per env step (traffic, PMC) and "
-                                 "the algorithmic figure can exceed the HBM peak."},
+                                 "every 8th launch, so the kernel moves fewer bytes per env step than that (traffic, PMC: "
+                                 "%s) and the algorithmic figure can exceed the HBM peak."
+                                 % (ab, ("%.0f B per env step" % (traffic / B)) if traffic else "not collected for this "
+                                    "board size")},
         }
         if world == 1 and not args.no_rollout:
             out["fused_rollout"] = fused_rollout(env, args.seed)
