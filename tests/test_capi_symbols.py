@@ -45,3 +45,44 @@ def test_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(TwixtHipError):
         TwixtBatchEnv(8, 4)
+
+
+def test_argument_errors_without_a_device():
+    """Every entry point rejects a NULL handle (and create its bad arguments) with TWX_E_ARG
+    and a message, before touching the device: no exception, no crash crosses the ABI."""
+    from twixt_for_open_spiel_amd import build, _lib
+    build.build()
+    lib = _lib.load()
+    E_ARG = -1
+    h = C.c_void_p()
+    assert lib.twx_create(8, 0, 0, 0, C.byref(h)) == E_ARG and b"batch" in lib.twx_last_error()
+    assert lib.twx_create(8, -5, 0, 0, C.byref(h)) == E_ARG
+    assert lib.twx_create(8, 4, 0, 0, None) == E_ARG
+    lib.twx_destroy(None)  # a no-op
+    calls = [
+        lambda: lib.twx_reset(None, None),
+        lambda: lib.twx_reset_boards(None, None, 0, None),
+        lambda: lib.twx_step(None, None, None, None),
+        lambda: lib.twx_step_random(None, 1, 1, None, None, None),
+        lambda: lib.twx_step_boards(None, None, 0, None, None, None),
+        lambda: lib.twx_step_random_boards(None, None, 0, 1, 1, None, None, None),
+        lambda: lib.twx_random_rollout(None, None, 0, 1, 10, None, None),
+        lambda: lib.twx_legal_mask(None, None, None, None),
+        lambda: lib.twx_legal_mask_boards(None, None, 0, None, None, None),
+        lambda: lib.twx_status(None, None, None, None, None),
+        lambda: lib.twx_status_boards(None, None, 0, None, None, None, None),
+        lambda: lib.twx_observation(None, None, None),
+        lambda: lib.twx_observation_boards(None, None, 0, None, None),
+        lambda: lib.twx_copy_boards(None, None, None, None, 0, None),
+        lambda: lib.twx_export_state(None, None, 0, None, None),
+        lambda: lib.twx_import_state(None, None, 0, None, None),
+        lambda: lib.twx_export_cells(None, None, 0, None, None),
+    ]
+    for i, call in enumerate(calls):
+        assert call() == E_ARG, i
+        assert lib.twx_last_error().decode().startswith("twx_"), i
+    buf = C.create_string_buffer(64)
+    assert lib.twx_action_to_string(8, 0, 64, buf, 64) == E_ARG      # action out of range
+    assert lib.twx_action_to_string(30, 0, 1, buf, 64) == E_ARG
+    assert lib.twx_cells_to_string(None, 8, 0, 0, 0, buf, 64) == E_ARG
+    assert lib.twx_board_size(None) < 0 and lib.twx_batch(None) < 0

@@ -511,3 +511,37 @@ def test_random_configurations(torch_mod, monkeypatch):
         compare_planes(env, ref["planes"], what=tag)
         assert np.array_equal(env.export_cells().cpu().numpy(), ref["cells"]), tag
         env.close()
+
+
+def test_argument_errors_with_a_handle(torch_mod):
+    """Bad arguments on a live handle: TWX_E_ARG + message, and the boards are untouched."""
+    import ctypes as C
+    import oracle_binding as ob
+    torch = torch_mod
+    env, other = make_env(8, 100), make_env(9, 100)
+    lib, h = env.lib, env._h
+    ids = torch.arange(4, dtype=torch.int32, device="cuda")
+    buf = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    i32 = lambda t: C.cast(p(t), C.POINTER(C.c_int32))
+    u32p = lambda t: C.cast(p(t), C.POINTER(C.c_uint32))
+    u8 = lambda t: C.cast(p(t), C.POINTER(C.c_uint8))
+    bad = [
+        lib.twx_step(h, None, None, None),                                  # actions NULL
+        lib.twx_step_boards(h, i32(ids), -1, i32(buf), None, None),          # negative count
+        lib.twx_step_boards(h, None, 4, i32(buf), None, None),               # ids NULL
+        lib.twx_reset_boards(h, None, 4, None),
+        lib.twx_legal_mask_boards(h, None, 101, u32p(buf), None, None),      # more rows than boards
+        lib.twx_export_state(h, None, 101, u32p(buf), None),
+        lib.twx_import_state(h, None, 101, u32p(buf), None),
+        lib.twx_export_cells(h, None, 101, u8(buf), None),
+        lib.twx_observation_boards(h, None, 101, p(buf), None),
+        lib.twx_random_rollout(h, None, 0, 1, -3, None, None),               # negative length
+        lib.twx_copy_boards(h, i32(ids), other._h, i32(ids), 4, None),       # board sizes differ
+    ]
+    assert bad == [-1] * len(bad), bad
+    assert lib.twx_last_error().decode() == "twx_copy_boards: board sizes differ"
+    torch.cuda.synchronize()
+    compare_planes(env, np.stack([ob.Board(8).planes()] * 100), what="after rejected calls")
+    env.close()
+    other.close()
