@@ -20,7 +20,10 @@
  *   - a handle is used from one host thread and one stream at a time (calls on it are
  *     ordered by that stream).  Between compactions the board state is log-structured
  *     (DESIGN.md): the step functions carry a host-side journal position as a launch
- *     argument, so a sequence of steps must not be replayed from a captured hipGraph;
+ *     argument, so a sequence of steps must not be replayed from a captured hipGraph
+ *     unless the handle was created with TWX_GRAPH_SAFE=1 in the environment (planes
+ *     rewritten in place every step, fixed batch order: every launch argument is then
+ *     constant; meant for small, launch-bound batches such as search leaves);
  *     every other entry point first materialises the journal and is unaffected.
  *   - tuning knobs read once by twx_create from the environment: TWX_JOURNAL_PERIOD
  *     (1..8, default 8; 1 = rewrite the planes every step), TWX_PINGPONG (0/1, default 1:

@@ -545,3 +545,34 @@ def test_argument_errors_with_a_handle(torch_mod):
     compare_planes(env, np.stack([ob.Board(8).planes()] * 100), what="after rejected calls")
     env.close()
     other.close()
+
+
+def test_hipgraph_replay(torch_mod, monkeypatch):
+    """TWX_GRAPH_SAFE=1 switches the host-side launch counters off (journal period 1, static
+    batch order, no alternating order): every launch of twx_step_random then has constant
+    arguments and a captured hipGraph of steps may be replayed: 4 steps captured once,
+    replayed 10 times."""
+    import oracle_binding as ob
+    torch = torch_mod
+    monkeypatch.setenv("TWX_GRAPH_SAFE", "1")
+    n, batch, seed = 8, 4096, 77
+    env = make_env(n, batch, first=3)
+    acts = torch.empty((4, batch), dtype=torch.int32, device="cuda")
+    stat = torch.empty((4, batch), dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        env.step_random(seed, True, actions_out=acts[0], status=stat[0])  # warm-up outside the capture
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for k in range(4):
+            env.step_random(seed, True, actions_out=acts[k], status=stat[k])
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    steps = 1 + 40
+    ref = ob.rollout_batch(n, seed, 3, batch, steps, True, want_trace=True)
+    compare_planes(env, ref["planes"], what="graph replay")
+    assert np.array_equal(acts.cpu().numpy().T, ref["actions"][:, -4:])
+    assert np.array_equal(stat.cpu().numpy().T, ref["status"][:, -4:])
+    env.close()

@@ -360,6 +360,13 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->launches = 0;
   e->dynamic = env_int("TWX_DYNAMIC", 1, 0, 1) != 0;
   e->dyn_static = env_int("TWX_DYNAMIC_STATIC", 0, 0, 1 << 20);  // 0 = automatic
+  if (env_int("TWX_GRAPH_SAFE", 0, 0, 1)) {
+    // no host-side launch counters: every step launch has constant arguments, so captured
+    // hipGraphs of steps may be replayed (the planes are rewritten in place every step)
+    e->period = 1;
+    e->pingpong = false;
+    e->dynamic = false;
+  }
   e->ticket = nullptr;
   e->ticket_base = TicketBases{};
   {
