@@ -81,13 +81,17 @@ __global__ __launch_bounds__(WAVE) void probe(uint4 *__restrict__ st, long bpad,
 // chunk; launches with (iter % 8 == 7) write everything (compaction); ~6 % of lanes also
 // write 3 scattered chunks (flood-fill dirt).  USE_DMA selects LDS-DMA loads.
 constexpr int CHJ = CH + 2;
-template <bool USE_DMA>
-__global__ __launch_bounds__(WAVE) void journal(uint4 *__restrict__ st, long bpad, uint32_t iter, int rev) {
+// TILED: the layout [batch of 64 boards][chunk][64] (one contiguous 39 KiB tile per wave)
+// instead of [chunk][board] (39 rows of 1 KiB, 16 MiB apart).
+template <bool USE_DMA, bool TILED = false>
+__global__ __launch_bounds__(WAVE) void journal(uint4 *__restrict__ st_, long bpad, uint32_t iter, int rev) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
   const int lane = threadIdx.x;
   const long blk = rev ? (long)(gridDim.x - 1 - blockIdx.x) : (long)blockIdx.x;
-  const long board = blk * WAVE + lane;
+  const long board = TILED ? (long)lane : blk * WAVE + lane;
+  uint4 *__restrict__ st = TILED ? st_ + blk * (long)CHJ * WAVE : st_;
+  if (TILED) bpad = WAVE;
   if constexpr (USE_DMA) {
 #pragma unroll
     for (int c = 0; c < CHJ; c++)
@@ -124,14 +128,14 @@ __global__ __launch_bounds__(WAVE) void journal(uint4 *__restrict__ st, long bpa
   }
 }
 
-template <bool USE_DMA>
+template <bool USE_DMA, bool TILED = false>
 float run_journal(uint4 *st, long B, int reps, int pingpong) {
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const size_t lds = CHJ * WAVE * 16;
-  for (int i = 0; i < 8; i++) hipLaunchKernelGGL(journal<USE_DMA>, dim3(B / WAVE), dim3(WAVE), lds, 0, st, B, i, pingpong ? (i & 1) : 0);
+  for (int i = 0; i < 8; i++) hipLaunchKernelGGL((journal<USE_DMA, TILED>), dim3(B / WAVE), dim3(WAVE), lds, 0, st, B, i, pingpong ? (i & 1) : 0);
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL(journal<USE_DMA>, dim3(B / WAVE), dim3(WAVE), lds, 0, st, B, 8 + i, pingpong ? (i & 1) : 0);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((journal<USE_DMA, TILED>), dim3(B / WAVE), dim3(WAVE), lds, 0, st, B, 8 + i, pingpong ? (i & 1) : 0);
   CK(hipEventRecord(b));
   CK(hipEventSynchronize(b));
   CK(hipGetLastError());
@@ -174,6 +178,8 @@ int main() {
     const double jb = (double)CHJ * B * 16 + B * 16.0 * (2 * 7 + CHJ) / 8.0 + 0.059 * 3 * 16 * B * 7 / 8.0;
     rep("journal K=8", run_journal<false>(st, B, 64, 0), jb);
     rep("journal K=8, ping-pong", run_journal<false>(st, B, 64, 1), jb);
+    rep("journal K=8, tiled layout", (run_journal<false, true>(st, B, 64, 0)), jb);
+    rep("journal K=8, tiled, ping-pong", (run_journal<false, true>(st, B, 64, 1)), jb);
     rep("journal K=8, LDS-DMA", run_journal<true>(st, B, 64, 0), jb);
     rep("journal K=8, LDS-DMA, ping-pong", run_journal<true>(st, B, 64, 1), jb);
   }

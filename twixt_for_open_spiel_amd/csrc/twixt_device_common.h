@@ -88,6 +88,24 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_FLUSH
 #endif
 
+// Where chunk c (16 bytes) of board b lives in the state array, in uint4 units.
+//   TWX_TILED=1: tiles of 64 boards, [tile][chunk][64] -- the 64 boards a wave works on are
+//     one contiguous CHT KiB block, whole DRAM pages per wave;
+//   TWX_TILED=0: rows, [chunk][board] -- a wave's CHT loads are 1 KiB each, bpad*16 bytes apart.
+// Either way the 64 lanes of a wave read 1 KiB contiguous per chunk.
+#ifndef TWX_TILED
+#define TWX_TILED 1
+#endif
+__host__ __device__ __forceinline__ long chunk_index(long c, long b, long bpad, int cht) {
+#if TWX_TILED
+  (void)bpad;
+  return ((b >> 6) * cht + c) * 64 + (b & 63);
+#else
+  (void)cht;
+  return c * bpad + b;
+#endif
+}
+
 constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush = 8, kFlagReverse = 16,
               kFlagRolling = 32,  // + bits 8..11: journal period, bits 12..27: batch stride of a wave
               kFlagDynamic = 64;  // batches after a wave's first are drawn from the ticket counters

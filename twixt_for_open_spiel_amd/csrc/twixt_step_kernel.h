@@ -102,7 +102,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b0];
+    for (int j = 0; j < NJ; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b0, bpad, CHT)];
 #pragma unroll
     for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
@@ -144,7 +144,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   auto prefetch = [&](int c0, int c1) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = c0; j < c1; j++) nxt[j] = gstate[(long)(chunk_of(j) < CHT ? chunk_of(j) : CHT - 1) * bpad + b1];
+    for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, bpad, CHT)];
     __builtin_amdgcn_sched_barrier(0);
   };
 #ifndef TWX_PF_A
@@ -498,17 +498,17 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   if (compact) {
 #pragma unroll
     for (int j = 0; j < NJ; j++)
-      if (wr && chunk_of(j) < CHT) state[(long)chunk_of(j) * bpad + board] = lds4[j * kWave + lane];
+      if (wr && chunk_of(j) < CHT) state[chunk_index(chunk_of(j), board, bpad, CHT)] = lds4[j * kWave + lane];
   } else {
     const int jc = CJ + (jpos >> 2);  // the journal chunk of slot jpos
     if (BPW == 64) {
       if (wr) {
-        state[(long)CS * bpad + board] = lds4[CS * kWave + lane];  // scalars
-        state[(long)jc * bpad + board] = lds4[jc * kWave + lane];
+        state[chunk_index(CS, board, bpad, CHT)] = lds4[CS * kWave + lane];  // scalars
+        state[chunk_index(jc, board, bpad, CHT)] = lds4[jc * kWave + lane];
       }
     } else {  // one store: lower half the scalars chunk, upper half the journal chunk
       const int c = half ? jc : CS;
-      if (wr) state[(long)c * bpad + board] = lds4[c * BPW + bl];
+      if (wr) state[chunk_index(c, board, bpad, CHT)] = lds4[c * BPW + bl];
     }
     STAMP(9);  // fixed stores (scalars + journal chunk)
     // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
@@ -518,14 +518,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
         dd &= dd - 1;
-        state[(long)c * bpad + board] = lds4[c * BPW + bl];
+        state[chunk_index(c, board, bpad, CHT)] = lds4[c * BPW + bl];
       }
     }
     STAMP(10);  // dirty flag chunks
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && chunk_of(j) < CHT) state[(long)chunk_of(j) * bpad + board] = lds4[j * kWave + lane];
+        if (was_reset && chunk_of(j) < CHT) state[chunk_index(chunk_of(j), board, bpad, CHT)] = lds4[j * kWave + lane];
     }
   }
   STAMP(11);  // reset lanes / compaction

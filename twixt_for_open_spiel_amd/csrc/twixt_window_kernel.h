@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
   {
     const long b0 = batch_board(idx);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) nxt[j] = gstate[(long)WGEO::hbm_chunk(j) * bpad + b0];
+    for (int j = 0; j < NJ; j++) nxt[j] = gstate[chunk_index(WGEO::hbm_chunk(j), b0, bpad, G::CHT)];
 #pragma unroll
     for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));
   }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     auto prefetch = [&](int c0, int c1) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = c0; j < c1; j++) nxt[j] = gstate[(long)WGEO::hbm_chunk(j) * bpad + b1];
+      for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index(WGEO::hbm_chunk(j), b1, bpad, G::CHT)];
       __builtin_amdgcn_sched_barrier(0);
     };
     constexpr int kPf1 = NJ / 3, kPf2 = 2 * NJ / 3;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < WG; k++)
-        gw[k] = was_reset ? initv[2 * (g0 + k) + 1] : gstate[(long)(2 * (g0 + k) + 1) * bpad + board];
+        gw[k] = was_reset ? initv[2 * (g0 + k) + 1] : gstate[chunk_index((2 * (g0 + k) + 1), board, bpad, G::CHT)];
       __builtin_amdgcn_sched_barrier(0);
       prefetch(kPf2, NJ);
 #pragma unroll
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                                              : __builtin_amdgcn_readlane((int)pend, s0));
       uint32_t *const scr = lds + SCR + fh * SCR_ROWS * 4;  // odd chunk of group i at scr + 4*i
       // all odd chunks of the board (a flood never follows a reset: move 0 makes no link)
-      if (c < W) *reinterpret_cast<u32x4 *>(scr + 4 * c) = gstate[(long)(2 * c + 1) * bpad + sboard];
+      if (c < W) *reinterpret_cast<u32x4 *>(scr + 4 * c) = gstate[chunk_index((2 * c + 1), sboard, bpad, G::CHT)];
       if (c == W) *reinterpret_cast<uint4 *>(scr + 4 * c) = make_uint4(0u, 0u, 0u, 0u);  // pad row: dirty mask in .x
       wave_sync();
       // journal slots 0..jpos (the new record included) onto the scratch: lane c takes slot c
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
       }
       // the odd chunks the fill changed go straight back to HBM
       if (live && c < W && ((scr[4 * W] >> c) & 1u))
-        state[(long)(2 * c + 1) * bpad + sboard] = *reinterpret_cast<const uint4 *>(scr + 4 * c);
+        state[chunk_index((2 * c + 1), sboard, bpad, G::CHT)] = *reinterpret_cast<const uint4 *>(scr + 4 * c);
       wave_sync();
     }
 
@@ -422,12 +422,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
 
     // ---- stream back: scalars + this launch's journal chunk; the shortcut's flag chunk;
     //      whole boards for auto-reset lanes ----
-    state[(long)CS * bpad + board] = lds4[ROW_SC * kWave + lane];
-    state[(long)(CJ + (jpos >> 2)) * bpad + board] = lds4[(ROW_J + (jpos >> 2)) * kWave + lane];
+    state[chunk_index(CS, board, bpad, G::CHT)] = lds4[ROW_SC * kWave + lane];
+    state[chunk_index((CJ + (jpos >> 2)), board, bpad, G::CHT)] = lds4[(ROW_J + (jpos >> 2)) * kWave + lane];
     if (__ballot(fast_dirty != 0u && !was_reset)) {
       if (fast_dirty && !was_reset) {
         const int gi = __ffs((int)fast_dirty) - 1;
-        state[(long)(2 * gi + 1) * bpad + board] = lds4[(ROW_O + gi - g0) * kWave + lane];
+        state[chunk_index((2 * gi + 1), board, bpad, G::CHT)] = lds4[(ROW_O + gi - g0) * kWave + lane];
       }
     }
     if (__ballot(was_reset)) {
@@ -435,12 +435,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         const uint4 *__restrict__ initc = init_chunks;
 #pragma unroll
         for (int i = 0; i < W; i++) {
-          state[(long)(2 * i) * bpad + board] = lds4[i * kWave + lane];
-          state[(long)(2 * i + 1) * bpad + board] = inwin(i) ? lds4[(ROW_O + i - g0) * kWave + lane] : initc[2 * i + 1];
+          state[chunk_index((2 * i), board, bpad, G::CHT)] = lds4[i * kWave + lane];
+          state[chunk_index((2 * i + 1), board, bpad, G::CHT)] = inwin(i) ? lds4[(ROW_O + i - g0) * kWave + lane] : initc[2 * i + 1];
         }
 #pragma unroll
         for (int k = 0; k < twx::kJournalChunks; k++)
-          state[(long)(CJ + k) * bpad + board] = lds4[(ROW_J + k) * kWave + lane];
+          state[chunk_index((CJ + k), board, bpad, G::CHT)] = lds4[(ROW_J + k) * kWave + lane];
       }
     }
     if (inb) {
