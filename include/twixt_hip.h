@@ -17,6 +17,8 @@
  *     Calls are asynchronous on that stream; the handle is re-entrant, there is
  *     no global mutable state (the reference's static BlockerMap, tb.h:150, has
  *     no counterpart).
+ *   - a handle's work always runs on the device it was created on; entry points select
+ *     that device for the duration of the call and put the caller's current device back.
  *   - a handle is used from one host thread and one stream at a time (calls on it are
  *     ordered by that stream).  Between compactions the board state is log-structured
  *     (DESIGN.md): the step functions carry a host-side journal position as a launch

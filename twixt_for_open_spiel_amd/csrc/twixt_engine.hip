@@ -210,8 +210,28 @@ int env_int(const char *name, int dflt, int lo, int hi) {
   return x < lo ? lo : x > hi ? hi : x;
 }
 
-// a handle's work always goes to the handle's device, whatever the caller's current one is
-#define TWX_USE(e) HIP_TRY(hipSetDevice((e)->device))
+// a handle's work always goes to the handle's device, whatever the caller's current one
+// is; the caller's current device is put back when the entry point returns
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  hipError_t err;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      changed = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define TWX_USE(e)                     \
+  DeviceGuard device_guard_((e)->device); \
+  HIP_TRY(device_guard_.err)
 
 // one env step (or a flush) on every board, or on the `nsub` boards listed in `ids`;
 // maintains the journal position
@@ -343,7 +363,8 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   if (n < TWX_MIN_BOARD_SIZE || n > TWX_MAX_BOARD_SIZE)  // tw.cc:139-144
     return fail(TWX_E_SIZE, "board_size out of range [5..24]: " + std::to_string(n));
   if (batch <= 0) return fail(TWX_E_ARG, "twx_create: batch must be positive");
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard device_guard_(device);
+  HIP_TRY(device_guard_.err);
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
   twx_env *e = new twx_env();
@@ -425,7 +446,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
 
 int twx_destroy(twx_env *e) {
   if (!e) return TWX_OK;
-  (void)hipSetDevice(e->device);
+  DeviceGuard device_guard_(e->device);
   (void)hipFree(e->state);
   (void)hipFree(e->tables);
   delete e;
