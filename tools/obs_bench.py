@@ -27,3 +27,11 @@ torch.cuda.synchronize()
 ms = a.elapsed_time(b) / K
 byts = out.numel() * 4
 print("twx_observation N=%d B=%d: %.3f ms, %.1f M boards/s, %.0f GB/s written" % (n, B, ms, B / ms / 1e3, byts / ms / 1e6))
+# write-only ceiling on the same buffer: a fill of the output tensor
+a.record()
+for _ in range(K):
+    out.fill_(1.0)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / K
+print("fill of the same %d MB buffer: %.3f ms, %.0f GB/s written" % (byts >> 20, ms, byts / ms / 1e6))
