@@ -19,17 +19,31 @@ for _ in range(704):
     env.step_random(1, True, want_actions=False, want_status=False)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
-env.lib.twx_debug_stamps(buf, 1)
-K = 64
-for _ in range(K):
-    env.step_random(1, True, want_actions=False, want_status=False)
-torch.cuda.synchronize()
-env.lib.twx_debug_stamps(buf, 0)
 names = ["loop/prev-store issue", "LDS fill + prefetch issue", "reset/replay", "legal mask", "select",
          "apply", "flood", "wait prefetch", "status store + loop end", "fixed stores", "dirty chunk stores",
          "reset lanes / compaction stores", "flood: pass setup", "flood: iterations", "flood: write-back"]
-tot = sum(buf[i] for i in range(15))
-wavesteps = K * (B // 64)
-for i, nm in enumerate(names):
-    print("%-28s %9.1f cycles/wave-step  %5.1f %%" % (nm, buf[i] / wavesteps, 100.0 * buf[i] / tot))
-print("total %.1f cycles/wave-step" % (tot / wavesteps))
+
+
+def run(k):
+    env.lib.twx_debug_stamps(buf, 1)
+    for _ in range(k):
+        env.step_random(1, True, want_actions=False, want_status=False)
+    torch.cuda.synchronize()
+    env.lib.twx_debug_stamps(buf, 0)
+    return [buf[i] for i in range(15)]
+
+
+# 704 prologue launches = 88 journal periods: the next 7 launches append to the journal, the
+# 8th compacts (rewrites every chunk).  The two kinds are reported separately.
+normal, compact = [0] * 15, [0] * 15
+R = 8
+for _ in range(R):
+    normal = [x + y for x, y in zip(normal, run(7))]
+    compact = [x + y for x, y in zip(compact, run(1))]
+for title, acc, launches in (("journal launches", normal, 7 * R), ("compaction launches", compact, R)):
+    tot = sum(acc)
+    wavesteps = launches * (B // 64)
+    print("--- %s ---" % title)
+    for i, nm in enumerate(names):
+        print("%-32s %9.1f cycles/wave-step  %5.1f %%" % (nm, acc[i] / wavesteps, 100.0 * acc[i] / tot))
+    print("total %.1f cycles/wave-step" % (tot / wavesteps))
