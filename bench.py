@@ -112,7 +112,7 @@ def fused_rollout(env, seed):
     return {"value": steps / (ms * 1e-3), "unit": "env steps/s", "launch_ms": ms, "env_steps": steps,
             "playouts_per_s": env.batch / (ms * 1e-3),
             "model": "whole random play-outs in one launch; HBM traffic 2*%d B per play-out (state read + "
-                     "written once)" % (16 * (2 * ((env.board_size ** 2 + 31) // 32) + 2))}
+                     "written once)" % (16 * (2 * ((env.board_size ** 2 + 31) // 32) + 3))}
 
 
 def shard_first_board(rank, batch_per_gpu):
