@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import twixt_for_open_spiel_amd._lib as L
 
 specs = sys.argv[1:]
-n, B = 24, 1 << 20
+n, B = int(os.environ.get("AB_N", "24")), 1 << 20  # AB_N: board size
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 loaded = {}
 

@@ -266,7 +266,12 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     // the first round; by default the last eighth of the rounds (at least two) is dynamic
     const long nbatch = ids ? (nsub + e->bpw - 1) / e->bpw : e->d.bpad / e->bpw;
     const long grid = nbatch < (long)e->waves ? nbatch : (long)e->waves;
-    const bool dyn = e->dynamic && grid % kTicketGroups == 0 && nbatch > grid;
+    // ... and the draws must stay well below what a counter sustains (~75 M tickets/s): a
+    // launch draws about 4 * grid / kTicketGroups tickets per counter in (nbatch / grid) batch
+    // times of ~10 us, so the tail is dynamic only while grid^2 <= 300 * nbatch.  Measured at
+    // B=2^20: +5..7 % for N >= 12 (2,048 waves and fewer), -12 % / -29 % at N=8 / N=5 (3,072 /
+    // 4,096 waves), which this rule keeps static.
+    const bool dyn = e->dynamic && grid % kTicketGroups == 0 && nbatch > grid && grid * grid <= 300 * nbatch;
     const long rounds = nbatch / grid;  // whole rounds
     long nstatic = e->dyn_static > 0 ? e->dyn_static : rounds - (rounds / 8 > 2 ? rounds / 8 : 2);
     if (nstatic > rounds) nstatic = rounds;
