@@ -82,7 +82,7 @@ def _build_cpp_driver(out):
     pkg = os.path.join(root, "twixt_for_open_spiel_amd")
     from twixt_for_open_spiel_amd import build
     build.build()
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
                            "-I/opt/rocm/include", os.path.join(pkg, "spiel_adapter", "mcts_driver.cc"), "-o", out,
                            "-L" + pkg, "-ltwixt_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + pkg,
                            "-Wl,-rpath,/opt/rocm/lib"])
@@ -111,3 +111,23 @@ def test_cpp_driver_plays_the_same_game(tmp_path, capsys):
     py_lines = re.findall(pat, capsys.readouterr().out)
     assert [int(m[2]) for m in cpp_lines] == hist and len(hist) == 6
     assert cpp_lines == py_lines
+
+
+@pytest.mark.gpu
+def test_cpp_driver_many_games(tmp_path):
+    """games > 1: independent trees share the device round trips; every game makes its six
+    moves (the driver aborts on a move the engine rejects) and game results are consistent."""
+    import re
+    import subprocess
+    exe = _build_cpp_driver(str(tmp_path / "mcts_driver"))
+    out = subprocess.run([exe, "8", "512", "6", "512", "5", "4"], capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    text = out.stdout.decode()
+    moves = re.findall(r"game (\d) move (\d+): player (\d) plays (\d+) \((\d+) visits\)", text)
+    assert len(moves) == 4 * 6
+    for g in range(4):
+        mine = [m for m in moves if int(m[0]) == g]
+        assert [int(m[1]) for m in mine] == list(range(6))
+        assert [int(m[2]) for m in mine] == [0, 1, 0, 1, 0, 1]       # nobody wins an 8x8 game in 6 moves
+        assert all(0 <= int(m[3]) < 64 and 1 <= int(m[4]) <= 512 for m in mine)
+    assert "%d simulations" % (4 * 6 * 512) in text

@@ -5,9 +5,14 @@
 // the same games; the Python one is the readable reference, this one removes the
 // interpreter from the loop.
 //
-//   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include mcts_driver.cc
+//   g++ -O2 -fopenmp -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include mcts_driver.cc
 //     -Ltwixt_for_open_spiel_amd -ltwixt_hip -L/opt/rocm/lib -lamdhip64 -o mcts_driver
-//   ./mcts_driver [board_size=12] [max_simulations=20000] [moves=0 (whole game)] [leaves=2048] [seed=1]
+//   ./mcts_driver [board_size=12] [max_simulations=20000] [moves=0 (whole game)] [leaves=2048] [seed=1] [games=1]
+//
+// games > 1: that many independent self-play games at once (self-play data generation).  Every
+// game has its own tree and root slot; the `leaves` of a device round trip are shared evenly,
+// the trees are worked on by one host thread each (OpenMP), the device work of all games goes
+// out as one batch.  games = 1 is exactly the single search above.
 #include <hip/hip_runtime_api.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -18,6 +23,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <new>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -26,11 +34,39 @@
 #define TWX(x) do { if ((x) != TWX_OK) { std::fprintf(stderr, "%s: %s\n", #x, twx_last_error()); std::exit(1); } } while (0)
 #define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
+// Bump allocator for one search tree: nodes and their arrays come out of 1 MiB blocks that
+// are recycled for the next move's tree, so building and dropping a tree of a few 10^4 nodes
+// costs no malloc / free traffic (which dominated once several trees were worked on at once).
+class Arena {
+ public:
+  void *Alloc(size_t bytes) {
+    bytes = (bytes + 15) & ~(size_t)15;
+    if (blocks_.empty() || used_ + bytes > kBlock) {
+      if (++cur_ >= (long)blocks_.size()) blocks_.emplace_back(new char[std::max(kBlock, bytes)]);
+      else if (bytes > kBlock) { blocks_[cur_].reset(new char[bytes]); }
+      used_ = 0;
+    }
+    void *p = blocks_[cur_].get() + used_;
+    used_ += bytes;
+    return p;
+  }
+  template <class T>
+  T *Array(size_t n) { return static_cast<T *>(Alloc(n * sizeof(T))); }
+  void Reset() { cur_ = -1; used_ = kBlock; }  // keep the blocks
+
+ private:
+  static constexpr size_t kBlock = 1 << 20;
+  std::vector<std::unique_ptr<char[]>> blocks_;
+  long cur_ = -1;
+  size_t used_ = kBlock;
+};
+
 // A node keeps its children's statistics in its own arrays (cn / cw, indexed like `legal`),
 // so that the UCT scan of a node reads contiguous memory; a child reaches its own counters
 // through (parent, slot).  Children are created in ascending action order -- an uncreated
 // child scores 1e9 in mcts.py and the first maximum wins -- so `created` children are
 // always the prefix legal[0..created) and the next new child is found without a scan.
+// Everything lives in the tree's arena; nothing is freed node by node.
 struct Node {
   Node *parent;
   int slot;           // index in the parent's arrays (-1 at the root)
@@ -39,27 +75,29 @@ struct Node {
   bool expanded = false;
   int terminal = 0;   // result if the game is over here
   double root_n = 0.0, root_w = 0.0;  // the root's own counters
-  std::vector<int> legal;
-  std::vector<double> cn, cw;  // per child: visits, summed return for this node's player
-  std::vector<std::unique_ptr<Node>> child;
-  size_t created = 0;
+  size_t nlegal = 0, created = 0;
+  int *legal = nullptr;
+  double *cn = nullptr, *cw = nullptr;  // per child: visits, summed return for this node's player
+  Node **child = nullptr;
   Node(Node *p, int sl, int a, int m) : parent(p), slot(sl), action(a), mover(m) {}
   double &n() { return parent ? parent->cn[slot] : root_n; }
   double &w() { return parent ? parent->cw[slot] : root_w; }
-  void Expand(std::vector<int> la, int to_move) {
+  void Expand(Arena *arena, const std::vector<int> &la, int to_move) {
     expanded = true;
-    legal = std::move(la);
     player = to_move;
-    cn.assign(legal.size(), 0.0);
-    cw.assign(legal.size(), 0.0);
-    child.resize(legal.size());
+    nlegal = la.size();
+    legal = arena->Array<int>(nlegal);
+    cn = arena->Array<double>(nlegal);
+    cw = arena->Array<double>(nlegal);
+    child = arena->Array<Node *>(nlegal);
+    for (size_t i = 0; i < nlegal; i++) { legal[i] = la[i]; cn[i] = 0.0; cw[i] = 0.0; child[i] = nullptr; }
   }
 };
 
 struct Leaf { int result, player; std::vector<int> legal; int final_result; };
 
 // wall-clock shares of a run (printed at the end): tree work on the host vs device round trips
-static double g_t[5];  // select, path replay, leaf query, play-outs, backup
+static double g_t[7];  // select, path replay, leaf query, play-outs, backup, new trees, batch assembly
 struct Timer {
   int slot;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -67,48 +105,53 @@ struct Timer {
   ~Timer() { g_t[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-// slots 0..L-1 are scratch leaves, slot L is the root (mcts.py: DeviceEvaluator)
+// slots 0..L-1 are scratch leaves, slots L..L+G-1 the roots of the G games (mcts.py: DeviceEvaluator)
 class Device {
  public:
-  Device(int n, int leaves) : n_(n), L_(leaves), W_(twx_mask_words(n)) {
-    TWX(twx_create(n, leaves + 1, 0, 0, &env_));
-    HIP(hipMalloc(&d_ids_, 4 * (L_ + 1)));
-    HIP(hipMalloc(&d_src_, 4 * (L_ + 1)));
-    HIP(hipMalloc(&d_act_, 4 * (L_ + 1)));
-    HIP(hipMalloc(&d_st_, L_ + 1));
-    HIP(hipMalloc(&d_res_, L_ + 1));
-    HIP(hipMalloc(&d_cp_, L_ + 1));
-    HIP(hipMalloc(&d_mask_, 4 * (size_t)W_ * (L_ + 1)));
-    std::vector<int32_t> iota(L_ + 1), root(L_ + 1, L_);
-    for (int i = 0; i <= L_; i++) iota[i] = i;
-    HIP(hipMemcpy(d_src_, root.data(), 4 * (L_ + 1), hipMemcpyHostToDevice));
-    HIP(hipMalloc(&d_iota_, 4 * (L_ + 1)));
-    HIP(hipMemcpy(d_iota_, iota.data(), 4 * (L_ + 1), hipMemcpyHostToDevice));
+  Device(int n, int leaves, int games, int threads)
+      : n_(n), L_(leaves), G_(games), W_(twx_mask_words(n)), threads_(threads) {
+    const int cap = L_ + G_;
+    TWX(twx_create(n, cap, 0, 0, &env_));
+    HIP(hipMalloc(&d_ids_, 4 * cap));
+    HIP(hipMalloc(&d_src_, 4 * cap));
+    HIP(hipMalloc(&d_act_, 4 * cap));
+    HIP(hipMalloc(&d_st_, cap));
+    HIP(hipMalloc(&d_res_, cap));
+    HIP(hipMalloc(&d_cp_, cap));
+    HIP(hipMalloc(&d_mask_, 4 * (size_t)W_ * cap));
+    HIP(hipMalloc(&d_iota_, 4 * cap));
+    std::vector<int32_t> iota(cap);
+    for (int i = 0; i < cap; i++) iota[i] = i;
+    HIP(hipMemcpy(d_iota_, iota.data(), 4 * cap, hipMemcpyHostToDevice));
   }
   ~Device() { twx_destroy(env_); }
 
-  int AdvanceRoot(int action) {
-    int32_t id = L_, a = action;
-    uint8_t st = 0;
-    HIP(hipMemcpy(d_ids_, &id, 4, hipMemcpyHostToDevice));
-    HIP(hipMemcpy(d_act_, &a, 4, hipMemcpyHostToDevice));
-    TWX(twx_step_boards(env_, d_ids_, 1, d_act_, d_st_, nullptr));
-    HIP(hipMemcpy(&st, d_st_, 1, hipMemcpyDeviceToHost));
-    if (st & TWX_ST_ILLEGAL) { std::fprintf(stderr, "illegal root move %d\n", action); std::exit(1); }
-    return st & TWX_ST_RESULT_MASK;
+  void ResetRoots() { TWX(twx_reset_boards(env_, d_iota_ + L_, G_, nullptr)); }
+  std::vector<Leaf> RootInfos() { return Query(d_iota_ + L_, G_); }
+  // one move per listed game; returns nothing: the next RootInfos() tells the results
+  void AdvanceRoots(const std::vector<int> &games, const std::vector<int> &actions) {
+    if (games.empty()) return;
+    std::vector<int32_t> ids(games.size()), acts(actions.begin(), actions.end());
+    for (size_t i = 0; i < games.size(); i++) ids[i] = L_ + games[i];
+    std::vector<uint8_t> st(games.size());
+    HIP(hipMemcpy(d_ids_, ids.data(), 4 * ids.size(), hipMemcpyHostToDevice));
+    HIP(hipMemcpy(d_act_, acts.data(), 4 * acts.size(), hipMemcpyHostToDevice));
+    TWX(twx_step_boards(env_, d_ids_, (int64_t)ids.size(), d_act_, d_st_, nullptr));
+    HIP(hipMemcpy(st.data(), d_st_, st.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < st.size(); i++)
+      if (st[i] & TWX_ST_ILLEGAL) { std::fprintf(stderr, "illegal root move %d\n", actions[i]); std::exit(1); }
   }
-  Leaf RootInfo() {
-    int32_t id = L_;
-    HIP(hipMemcpy(d_ids_, &id, 4, hipMemcpyHostToDevice));
-    return Query(d_ids_, 1)[0];
-  }
-  std::vector<Leaf> Evaluate(const std::vector<std::vector<int>> &paths, uint32_t seed) {
+  // paths[i]: actions from the root of game game_of[i] to leaf i
+  std::vector<Leaf> Evaluate(const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of,
+                             uint32_t seed) {
     const int k = (int)paths.size();
     std::unique_ptr<Timer> tm(new Timer(1));
-    TWX(twx_copy_boards(env_, d_iota_, env_, d_src_, k, nullptr));  // root -> slots 0..k-1
+    std::vector<int32_t> rows(k), acts;
+    for (int i = 0; i < k; i++) rows[i] = L_ + game_of[i];
+    HIP(hipMemcpy(d_src_, rows.data(), 4 * k, hipMemcpyHostToDevice));
+    TWX(twx_copy_boards(env_, d_iota_, env_, d_src_, k, nullptr));  // roots -> slots 0..k-1
     size_t depth = 0;
     for (auto &p : paths) depth = std::max(depth, p.size());
-    std::vector<int32_t> rows, acts;
     for (size_t t = 0; t < depth; t++) {
       rows.clear();
       acts.clear();
@@ -131,11 +174,6 @@ class Device {
     for (int i = 0; i < k; i++) out[i].final_result = st[i] & TWX_ST_RESULT_MASK;
     return out;
   }
-  void ResetRoot() {
-    int32_t id = L_;
-    HIP(hipMemcpy(d_ids_, &id, 4, hipMemcpyHostToDevice));
-    TWX(twx_reset_boards(env_, d_ids_, 1, nullptr));
-  }
 
  private:
   std::vector<Leaf> Query(const int32_t *ids, int k) {
@@ -151,6 +189,7 @@ class Device {
     HIP(hipMemcpy(cp.data(), d_cp_, k, hipMemcpyDeviceToHost));
     HIP(hipMemcpy(mask.data(), d_mask_, 4 * (size_t)W_ * k, hipMemcpyDeviceToHost));
     std::vector<Leaf> out(k);
+#pragma omp parallel for schedule(static) num_threads(threads_) if (threads_ > 1 && k >= 1024)
     for (int i = 0; i < k; i++) {
       out[i].result = res[i];
       out[i].player = cp[i];
@@ -163,7 +202,7 @@ class Device {
     }
     return out;
   }
-  int n_, L_, W_;
+  int n_, L_, G_, W_, threads_;
   twx_env *env_ = nullptr;
   int32_t *d_ids_, *d_src_, *d_act_, *d_iota_;
   uint8_t *d_st_, *d_res_;
@@ -205,34 +244,35 @@ static void UctValues(const double *cn, const double *cw, double *val, size_t m,
   UctValuesScalar(cn, cw, val, 0, m, logn, c);
 }
 
+// the search tree of one game for one move (mcts.py BatchedMCTS)
 class Mcts {
  public:
-  Mcts(Device *dev, int leaves, uint32_t seed, double c = 2.0) : dev_(dev), L_(leaves), seed_(seed), c_(c) {}
-  int Search(int root_player, const std::vector<int> &root_legal, long max_sims, long *best_visits) {
-    Node root(nullptr, -1, -1, -1);
-    root.Expand(root_legal, root_player);
-    for (long done = 0; done < max_sims;) {
-      const long k = std::min<long>(L_, max_sims - done);
-      std::vector<Node *> leaves(k);
-      std::vector<std::vector<int>> paths(k);
-      {
-        Timer tm(0);
-        for (long i = 0; i < k; i++) leaves[i] = Select(&root, &paths[i]);
-      }
-      std::vector<Leaf> out = dev_->Evaluate(paths, seed_ + (uint32_t)batches_++);
-      Timer tm(4);
-      for (long i = 0; i < k; i++) {
-        Node *leaf = leaves[i];
-        if (out[i].result != 0) leaf->terminal = out[i].result;
-        else if (!leaf->expanded) leaf->Expand(std::move(out[i].legal), out[i].player);
-        Backup(leaf, out[i].result != 0 ? out[i].result : out[i].final_result);
-      }
-      done += k;
+  explicit Mcts(double c = 2.0) : c_(c) {}
+  void Begin(int root_player, const std::vector<int> &root_legal) {
+    arena_.Reset();  // drops the previous move's tree
+    root_ = new (arena_.Alloc(sizeof(Node))) Node(nullptr, -1, -1, -1);
+    root_->Expand(&arena_, root_legal, root_player);
+  }
+  // k descents with virtual loss; the leaves and their paths are appended to the outputs
+  void SelectBatch(long k, std::vector<Node *> *leaves, std::vector<std::vector<int>> *paths) {
+    for (long i = 0; i < k; i++) {
+      paths->emplace_back();
+      leaves->push_back(Select(root_, &paths->back()));
     }
+  }
+  void ApplyBatch(Node *const *leaves, Leaf *out, long k) {
+    for (long i = 0; i < k; i++) {
+      Node *leaf = leaves[i];
+      if (out[i].result != 0) leaf->terminal = out[i].result;
+      else if (!leaf->expanded) leaf->Expand(&arena_, out[i].legal, out[i].player);
+      Backup(leaf, out[i].result != 0 ? out[i].result : out[i].final_result);
+    }
+  }
+  int Best(long *best_visits) const {
     int best = -1;
     long bv = -1;
-    for (size_t i = 0; i < root.created; i++)  // ascending action id; first maximum wins
-      if ((long)root.cn[i] > bv) { bv = (long)root.cn[i]; best = root.legal[i]; }
+    for (size_t i = 0; i < root_->created; i++)  // ascending action id; first maximum wins
+      if ((long)root_->cn[i] > bv) { bv = (long)root_->cn[i]; best = root_->legal[i]; }
     *best_visits = bv;
     return best;
   }
@@ -241,12 +281,12 @@ class Mcts {
   // mcts.py BatchedMCTS._select: same order, same double arithmetic (w/n + c*sqrt(log N / n)).
   // The values are computed first (vectorised, UctValues), the arg-max scan follows.
   size_t BestChild(Node *node) {
-    const size_t m = node->legal.size();
+    const size_t m = node->nlegal;
     if (node->created < m) return node->created;  // the first uncreated child scores 1e9
     const double logn = std::log(node->n());
     val_.resize(m);
     double *val = val_.data();
-    UctValues(node->cn.data(), node->cw.data(), val, m, logn, c_);
+    UctValues(node->cn, node->cw, val, m, logn, c_);
     size_t best = 0;
     double best_v = -1e30;
     for (size_t i = 0; i < m; i++)
@@ -261,10 +301,10 @@ class Mcts {
       if (node->terminal != 0 || !node->expanded) return node;
       const size_t i = BestChild(node);
       if (!node->child[i]) {
-        node->child[i].reset(new Node(node, (int)i, node->legal[i], node->player));
+        node->child[i] = new (arena_.Alloc(sizeof(Node))) Node(node, (int)i, node->legal[i], node->player);
         node->created = i + 1;
       }
-      node = node->child[i].get();
+      node = node->child[i];
       path->push_back(node->action);
     }
   }
@@ -276,13 +316,25 @@ class Mcts {
       if (node->mover >= 0) node->w() += r[node->mover];
     }
   }
-  Device *dev_;
-  long L_;
-  uint32_t seed_;
   double c_;
-  long batches_ = 0;
+  Arena arena_;
+  Node *root_ = nullptr;
   std::vector<double> val_;
 };
+
+// host threads for the trees: the cores this process may really use (the cgroup quota caps
+// what the affinity mask shows: an oversubscribed OpenMP team spins itself to a standstill)
+static int HostCores() {
+  int cores = (int)std::thread::hardware_concurrency();
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32];
+    long period = 0;
+    if (std::fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && q[0] != 'm')
+      cores = std::min(cores, std::max(1, (int)((std::atol(q) + period / 2) / period)));
+    std::fclose(f);
+  }
+  return std::max(1, cores);
+}
 
 int main(int argc, char **argv) {
   const int n = argc > 1 ? std::atoi(argv[1]) : 12;
@@ -290,27 +342,75 @@ int main(int argc, char **argv) {
   const int max_moves = argc > 3 ? std::atoi(argv[3]) : 0;
   const int leaves = argc > 4 ? std::atoi(argv[4]) : 2048;
   const uint32_t seed = argc > 5 ? (uint32_t)std::atol(argv[5]) : 1u;
-  Device dev(n, leaves);
-  dev.ResetRoot();
-  Mcts mcts(&dev, leaves, seed);
+  const int games = argc > 6 ? std::atoi(argv[6]) : 1;
+  if (games < 1 || leaves < games) { std::fprintf(stderr, "need 1 <= games <= leaves\n"); return 1; }
+  const long per_game = leaves / games;  // leaves of one game per device round trip
+  const int threads = std::min(games, HostCores());
+  Device dev(n, leaves, games, threads);
+  dev.ResetRoots();
+  std::vector<Mcts> mcts(games);
+  std::vector<int> result(games, 0), moves(games, 0);
   const auto t0 = std::chrono::steady_clock::now();
-  long total = 0;
-  int moves = 0, result = 0;
+  long total = 0, batches = 0;
   for (;;) {
-    const Leaf info = dev.RootInfo();
-    result = info.result;
-    if (result != 0 || (max_moves > 0 && moves >= max_moves)) break;
-    long visits = 0;
-    const int a = mcts.Search(info.player, info.legal, sims, &visits);
-    std::printf("move %d: player %d plays %d (%ld visits)\n", moves, info.player, a, visits);
-    dev.AdvanceRoot(a);
-    total += sims;
-    moves++;
+    const std::vector<Leaf> info = dev.RootInfos();
+    std::vector<int> live;
+    for (int g = 0; g < games; g++) {
+      result[g] = info[g].result;
+      if (result[g] == 0 && !(max_moves > 0 && moves[g] >= max_moves)) live.push_back(g);
+    }
+    if (live.empty()) break;
+    const int nl = (int)live.size();
+    {
+      Timer tm(5);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (nl > 1)
+      for (int j = 0; j < nl; j++) mcts[live[j]].Begin(info[live[j]].player, info[live[j]].legal);
+    }
+    for (long done = 0; done < sims;) {
+      const long k = std::min<long>(per_game, sims - done);
+      std::vector<std::vector<Node *>> leaf(nl);
+      std::vector<std::vector<std::vector<int>>> path(nl);
+      {
+        Timer tm(0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (nl > 1)
+        for (int j = 0; j < nl; j++) mcts[live[j]].SelectBatch(k, &leaf[j], &path[j]);
+      }
+      std::vector<std::vector<int>> paths;
+      std::vector<int> game_of;
+      {
+        Timer tm(6);
+        paths.reserve(nl * k);
+        game_of.reserve(nl * k);
+        for (int j = 0; j < nl; j++)
+          for (long i = 0; i < k; i++) { paths.push_back(std::move(path[j][i])); game_of.push_back(live[j]); }
+      }
+      std::vector<Leaf> out = dev.Evaluate(paths, game_of, seed + (uint32_t)batches++);
+      {
+        Timer tm(4);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (nl > 1)
+        for (int j = 0; j < nl; j++) mcts[live[j]].ApplyBatch(leaf[j].data(), out.data() + (size_t)j * k, k);
+      }
+      done += k;
+    }
+    std::vector<int> acts;
+    for (int g : live) {
+      long visits = 0;
+      const int a = mcts[g].Best(&visits);
+      if (games == 1) std::printf("move %d: player %d plays %d (%ld visits)\n", moves[g], info[g].player, a, visits);
+      else std::printf("game %d move %d: player %d plays %d (%ld visits)\n", g, moves[g], info[g].player, a, visits);
+      acts.push_back(a);
+      moves[g]++;
+      total += sims;
+    }
+    dev.AdvanceRoots(live, acts);
   }
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  std::printf("result %d after %d moves; %ld simulations in %.2f s = %.0f simulations/s\n", result, moves, total, dt,
-              total / dt);
-  std::printf("time: select %.2f s, path replay %.2f s, leaf query %.2f s, play-outs %.2f s, backup %.2f s\n", g_t[0],
-              g_t[1], g_t[2], g_t[3], g_t[4]);
+  for (int g = 0; g < games; g++)
+    std::printf("%sresult %d after %d moves\n", games == 1 ? "" : ("game " + std::to_string(g) + ": ").c_str(), result[g],
+                moves[g]);
+  std::printf("%ld simulations in %.2f s = %.0f simulations/s (%d game%s, %d leaves per round trip, %d host thread%s)\n",
+              total, dt, total / dt, games, games == 1 ? "" : "s", leaves, threads, threads == 1 ? "" : "s");
+  std::printf("time: select %.2f s, path replay %.2f s, leaf query %.2f s, play-outs %.2f s, backup %.2f s, "
+              "new trees %.2f s, batch assembly %.2f s\n", g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5], g_t[6]);
   return 0;
 }
