@@ -23,6 +23,7 @@
  *     ordered by that stream).  Between compactions the board state is log-structured
  *     (DESIGN.md): the step functions carry a host-side journal position as a launch
  *     argument, so a sequence of steps must not be replayed from a captured hipGraph
+ *     (the step functions return TWX_E_ARG on a capturing stream)
  *     unless the handle was created with TWX_GRAPH_SAFE=1 in the environment (planes
  *     rewritten in place every step, fixed batch order: every launch argument is then
  *     constant; meant for small, launch-bound batches such as search leaves);

@@ -576,3 +576,23 @@ def test_hipgraph_replay(torch_mod, monkeypatch):
     assert np.array_equal(acts.cpu().numpy().T, ref["actions"][:, -4:])
     assert np.array_equal(stat.cpu().numpy().T, ref["status"][:, -4:])
     env.close()
+
+
+def test_capture_refused_on_a_default_handle(torch_mod):
+    """A default handle carries host-side launch counters, so capturing its step functions is
+    refused with an error instead of producing a graph that would replay stale arguments."""
+    from twixt_for_open_spiel_amd import TwixtHipError
+    torch = torch_mod
+    env = make_env(8, 256)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        env.step_random(1, True, want_actions=False, want_status=False)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(TwixtHipError, match="TWX_GRAPH_SAFE"):
+        with torch.cuda.graph(g, stream=side):
+            env.step_random(1, True, want_actions=False, want_status=False)
+    torch.cuda.synchronize()
+    env.step_random(1, True, want_actions=False, want_status=False)   # the handle is still usable
+    torch.cuda.synchronize()
+    env.close()

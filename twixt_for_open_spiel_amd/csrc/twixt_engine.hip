@@ -240,6 +240,14 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   TWX_USE(e);
   const bool flush = (flags & kFlagFlush) != 0;
   const bool whole_step = !ids && rsteps == 1 && !flush;
+  if (e->period > 1 || e->pingpong || e->dynamic) {
+    // launch arguments change from call to call (journal position, batch order, ticket
+    // bases): a captured graph would replay stale ones and silently skip or repeat boards
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(TWX_E_ARG, "step functions cannot be captured into a hipGraph on this handle: create it with "
+                             "TWX_GRAPH_SAFE=1");
+  }
   if (!whole_step && !flush && e->journal_live) {
     // journals belong to the whole-batch step launches: subset and roll-out launches work
     // on materialised planes and rewrite their boards directly
