@@ -219,7 +219,7 @@ def main():
                          "moved_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                         "kernel": ("step_kernel64_small<%d, false>" if 2 * ((n * n + 31) // 32) + 3 <= 20
+                         "kernel": ("step_kernel64_small<%d, false>" if 2 * ((n * n + 31) // 32) + 3 <= 25
                                     else "step_kernel64<%d, false>") % n,
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": ab,

@@ -47,6 +47,10 @@ int fail(int code, const std::string &msg) {
       return fail(TWX_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// board sizes whose state is at most this many chunks use the several-waves-per-SIMD build
+#ifndef TWX_SMALL_CHT
+#define TWX_SMALL_CHT 25  // N <= 18: measured +19 % (N=17), +7 % (N=18); -3 % / -6 % at N=19 / 20
+#endif
 #include "twixt_device_common.h"
 #include "twixt_step_kernel.h"
 #ifdef TWX_ENABLE_WINDOW
@@ -67,7 +71,7 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
                      actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, ticket, ticket_base, nstatic)
   if (bpw == 64) {
-    if constexpr (twx::Geo<N>::CHT <= 20) {
+    if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT) {
       if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
     } else {
       if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
@@ -91,7 +95,7 @@ int step_occupancy(int bpw) {
   int blocks = 0;
   hipError_t e;
   if (bpw == 64) {
-    if constexpr (twx::Geo<N>::CHT <= 20)
+    if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT)
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64_small<N, false>, kWave, lds_bytes);
     else
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64<N, false>, kWave, lds_bytes);

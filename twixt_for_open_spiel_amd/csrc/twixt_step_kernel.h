@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 }
 
 
-// small boards (LDS image <= 20 KiB, N <= 16): several waves per SIMD fit, so no
+// small boards (LDS image <= 25 KiB, N <= 18; TWX_SMALL_CHT): several waves per SIMD fit, so no
 // one-wave-per-SIMD register budget; the compiler keeps it within 256 registers
 template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_kernel64_small(
