@@ -563,8 +563,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 
 // small boards (LDS image <= 25 KiB, N <= 18; TWX_SMALL_CHT): several waves per SIMD fit, so no
 // one-wave-per-SIMD register budget; the compiler keeps it within 256 registers
+#ifndef TWX_SMALL_MIN_WAVES
+#define TWX_SMALL_MIN_WAVES 2
+#endif
 template <int N, bool SUB>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 8))) void step_kernel64_small(
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TWX_SMALL_MIN_WAVES, 8))) void step_kernel64_small(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
