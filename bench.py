@@ -5,19 +5,25 @@ Metric (BASELINE.json): env steps/sec on random-action rollouts at board_size=24
 batch=2^20 per GPU.  One bench "step" = one twx_step_random launch = one env step
 on every board of the batch (terminal boards auto-reset and play move 0 in the
 same launch, so a launch is exactly B env steps).  State lives in HBM between
-launches (step-granular model): algorithmic traffic
-2*656+8 = 1320 B per env step at N=24.
+launches (step-granular model).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Boards are independent: every rank owns a contiguous shard of global board ids,
-no collective is on the data path (only the timing barrier / max).
+Multi-GPU: boards never interact, so rank r owns the contiguous
+global board ids [r*B, (r+1)*B) on GPU r and there is NO collective on the data path and
+none inside the timed region.  `--gpus N` without a launcher (WORLD_SIZE unset) makes this
+script start the N rank processes itself, before it has touched a GPU; under
+torch.distributed.run it is one of the ranks.  Either way the ranks meet on a CPU (gloo)
+group for the start / end barriers and for handing their clocks to rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,10 +33,22 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES = {24: 1320, 12: 348, 8: 168}  # 2*S(N)+8
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                     # same guide: measured float4-copy ceiling
+MIN_TIMED_MS = 50.0                       # the K-step block is repeated until this much GPU time
+TRAFFIC_FILE = os.path.join("profiles", "traffic_step_kernel_n24.json")
+JOURNAL_PERIOD = 8                        # twixt_geom.h kJournalSlots: every 8th launch compacts
 
 
 def algo_bytes(n):
     return ALGO_BYTES.get(n, 2 * (9 * ((n * n + 7) // 8) + 8) + 8)
+
+
+def design_bytes(n):
+    """Bytes this design moves per env step by construction: every launch
+    reads the board's CHT = 2W+3 chunks of 16 B; 7 launches in 8 write the scalars chunk and one
+    journal chunk (32 B), the 8th rewrites all CHT chunks.  (Flag chunks a flood fill dirtied and
+    auto-reset boards add about 2 B.)"""
+    cht = 2 * ((n * n + 31) // 32) + 3
+    return 16.0 * cht + ((JOURNAL_PERIOD - 1) * 32.0 + 16.0 * cht) / JOURNAL_PERIOD
 
 
 def host_cores():
@@ -54,10 +72,9 @@ def host_cores():
 def cpu_baseline(n, seed, budget_s=12.0):
     """Times the CPU oracle (the scalar port of the reference's algorithm) on all
     host cores with the same policy and workload shape.  Checker code used as a
-    *reported baseline only*."""
+    *reported baseline only*; its budget does not depend on --steps."""
     lib_path = os.path.join(ROOT, "oracle", "libtwixt_oracle.so")
     if not os.path.exists(lib_path):
-        import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libtwixt_oracle.so"],
                               stdout=subprocess.DEVNULL)
     lib = C.CDLL(lib_path)
@@ -79,19 +96,40 @@ def cpu_baseline(n, seed, budget_s=12.0):
                       % (nboards, nsteps, n, cores, dt)}
 
 
+def active_knobs():
+    """TWX_* tuning knobs twx_create would read from this environment (they change what the
+    kernel moves, so a committed traffic measurement does not describe such a run)."""
+    return sorted(k for k in os.environ if k.startswith("TWX_") and k != "TWX_CPU_THREADS")
+
+
 def measured_traffic(n, batch):
-    """HBM bytes per launch of step_kernel<N> from the committed rocprofv3 PMC passes
-    (profiles/traffic_step_kernel_n24.json: FETCH_SIZE x2 per the gfx950 correction +
-    WRITE_SIZE).  Counters cannot be collected inside this process; None if the
-    committed measurement does not cover this workload."""
-    path = os.path.join(ROOT, "profiles", "traffic_step_kernel_n24.json")
-    if n != 24 or not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic_step_kernel_n24.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE).  Counters cannot be collected inside this process, so
+    the file is only believed when it was measured on THIS library: it carries the hash of
+    the sources (and of the binary) it was taken on, the workload and the knobs.  Returns
+    (bytes or None, provenance dict)."""
+    from twixt_for_open_spiel_amd import build as b
+    src = {"file": TRAFFIC_FILE, "source_stamp_now": b.source_stamp(), "lib_sha256_now": b.lib_stamp()}
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
         with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_env_step"]) * batch
-    except (OSError, ValueError, KeyError):
-        return None
+            js = json.load(f)
+    except (OSError, ValueError):
+        src["rejected"] = "file missing or unreadable"
+        return None, src
+    src["source_stamp_measured"] = js.get("source_stamp")
+    src["lib_sha256_measured"] = js.get("lib_sha256")
+    src["measured_by"] = js.get("method")
+    if js.get("board_size") != n or js.get("batch") != batch:
+        src["rejected"] = "measured for N=%s, B=%s" % (js.get("board_size"), js.get("batch"))
+    elif active_knobs():
+        src["rejected"] = "tuning knobs set: " + ",".join(active_knobs())
+    elif js.get("source_stamp") != src["source_stamp_now"] and js.get("lib_sha256") != src["lib_sha256_now"]:
+        src["rejected"] = "measured on another build of libtwixt_hip.so"
+    else:
+        return float(js["hbm_bytes_per_launch"]), src
+    return None, src
 
 
 def fused_rollout(env, seed):
@@ -115,20 +153,48 @@ def fused_rollout(env, seed):
                      "written once)" % (16 * (2 * ((env.board_size ** 2 + 31) // 32) + 3))}
 
 
+def observation_rate(env, nboards, reps=10):
+    """Secondary: twx_observation on the first `nboards` boards, mid-game
+    states.  Write-bound: 12*N*(N-2) floats per board against a state of a few hundred bytes."""
+    import torch
+    n = env.board_size
+    out = env.observation(count=nboards)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        env.observation(count=nboards, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    per_board = 12 * n * (n - 2) * 4
+    gbs = per_board * nboards / (ms * 1e-3) / 1e9
+    return {"value": nboards / (ms * 1e-3), "unit": "boards/s", "boards": nboards, "launch_ms": ms,
+            "bytes_written_per_board": per_board, "written_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+            "kernel": "observation_kernel", "bound": "hbm (writes)"}
+
+
 def shard_first_board(rank, batch_per_gpu):
     """Rank r owns the contiguous global board ids [r*B, (r+1)*B)."""
     return rank * batch_per_gpu
 
 
-def max_over_ranks(value, dist, device):
-    """Whole-job time = the slowest rank's time."""
-    import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+def aggregate(per_rank, batch_per_gpu, steps, blocks):
+    """Whole-job figures from the ranks' own clocks: value = all env steps / the slowest rank's
+    elapsed time.  per_rank: list of dicts with rank, first_board_id, elapsed_s, kernel_ms."""
+    per_rank = sorted(per_rank, key=lambda r: r["rank"])
+    world = len(per_rank)
+    assert [r["rank"] for r in per_rank] == list(range(world)), "a rank is missing or doubled"
+    for r in per_rank:
+        assert r["first_board_id"] == shard_first_board(r["rank"], batch_per_gpu), "shards must tile the id range"
+    elapsed = max(r["elapsed_s"] for r in per_rank)
+    total = float(batch_per_gpu) * world * steps * blocks
+    return {"value": total / elapsed, "elapsed_s": elapsed, "total_env_steps": total,
+            "ms_per_step": elapsed / (steps * blocks) * 1e3,
+            "per_rank_value": [batch_per_gpu * steps * blocks / r["elapsed_s"] for r in per_rank]}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -138,105 +204,221 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--prologue", type=int, default=700,
                     help="untimed setup steps that spread the boards over all game phases")
-    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
-                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU and no library: a step is a short sleep (tests the launch, shard and "
+                         "aggregation plumbing on CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-observation", action="store_true", help="skip the secondary observation measurement")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
-    from twixt_for_open_spiel_amd import TwixtBatchEnv
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    if args.share_gpu:
-        local = 0
-    torch.cuda.set_device(local)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N rank processes (rank r -> GPU r).  Nothing in
+    this process has touched a GPU (device_count() does not initialise one)."""
+    n = args.gpus
+    if not args.dry_run and not args.share_gpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible (use --share-gpu to rehearse "
+                             "the ranks on one device)" % (n, have))
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        time.sleep(0.05)
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                for o in live:  # the others would wait for it in a barrier
+                    procs[o].terminate()
+    return rc
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args))
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != args.gpus:
+            raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    dist = None
     if world > 1:
+        import datetime
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend=args.backend)
+        # CPU group: barriers outside the timed region and the ranks' clocks -> rank 0.  The data
+        # path has no exchange step, so there is no RCCL communicator to build.
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
 
-    n, B = args.board_size, args.batch
-    env = TwixtBatchEnv(n, B, local, first_board_id=shard_first_board(rank, B))
+    n, B, K = args.board_size, args.batch, args.steps
+    first = shard_first_board(rank, B)
+    dev = 0 if args.share_gpu else local
 
-    def sync_all():
-        if world > 1:
+    if args.dry_run:
+        env = None
+
+        def launch():
+            time.sleep(2e-4)
+
+        def sync():
+            pass
+    else:
+        import torch
+        from twixt_for_open_spiel_amd import TwixtBatchEnv
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= dev:
+            raise SystemExit("rank %d: HIP device %d not available (%d visible)" % (rank, dev, torch.cuda.device_count()))
+        torch.cuda.set_device(dev)
+        env = TwixtBatchEnv(n, B, dev, first_board_id=first)
+
+        def launch():
+            env.step_random(args.seed, True, want_actions=False, want_status=False)
+
+        def sync():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.prologue + args.warmup):
-        env.step_random(args.seed, True, want_actions=False, want_status=False)
-    sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(0 if args.dry_run else args.prologue):
+        launch()
+    sync()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        env.step_random(args.seed, True, want_actions=False, want_status=False)
-    ev1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
-    if world > 1:
-        elapsed = max_over_ranks(elapsed, dist, "cuda" if args.backend == "nccl" else "cpu")
+    for _ in range(args.warmup):
+        launch()
+    sync()
+    est_ms = (time.perf_counter() - t0) * 1e3 / max(1, args.warmup)  # per launch, incl. host overhead
+    # a K-step block shorter than MIN_TIMED_MS is repeated: the figure must not hang on 3 ms
+    blocks = 1
+    if args.warmup > 0 and est_ms * K < MIN_TIMED_MS:
+        blocks = int(math.ceil(MIN_TIMED_MS / (est_ms * K)))
+    if dist is not None:
+        import torch
+        t = torch.tensor([blocks], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blocks = int(t.item())
 
-    res, mc, _ = env.status()
-    hist = torch.bincount(res.to(torch.int64), minlength=4).tolist()
+    elapsed, kernel_ms_sum = 0.0, 0.0
+    barrier()
+    for _ in range(blocks):  # each block: EXACTLY K launches between two device synchronisations
+        sync()
+        if env is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if env is not None:
+            ev0.record()
+        for _ in range(K):
+            launch()
+        if env is not None:
+            ev1.record()
+        sync()
+        elapsed += time.perf_counter() - t0
+        if env is not None:
+            kernel_ms_sum += ev0.elapsed_time(ev1)  # HIP events on the launch stream
+    barrier()
+    kernel_ms = kernel_ms_sum / (K * blocks) if env is not None else elapsed * 1e3 / (K * blocks)
+
+    hist = None
+    if env is not None:
+        res, _, _ = env.status()
+        hist = torch.bincount(res.to(torch.int64), minlength=4).tolist()
+    mine = {"rank": rank, "first_board_id": first, "device": dev, "elapsed_s": elapsed, "kernel_ms": kernel_ms,
+            "result_hist": hist}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
-        total_steps = float(B) * world * args.steps
-        value = total_steps / elapsed
-        ab = algo_bytes(n)
-        achieved = ab * B / (kernel_ms * 1e-3) / 1e9
-        traffic = measured_traffic(n, B)
+        agg = aggregate(per_rank, B, K, blocks)
+        ab, db = algo_bytes(n), design_bytes(n)
+        traffic, traffic_src = (None, {"rejected": "dry run"}) if args.dry_run else measured_traffic(n, B)
+        moved = traffic if traffic is not None else db * B  # bytes per launch the roofline is priced on
+        achieved = moved / (kernel_ms * 1e-3) / 1e9
+        small = 2 * ((n * n + 31) // 32) + 3 <= 25
         out = {
             "metric": "env steps/sec at board_size=%d, batch=%d per GPU, random-action rollouts" % (n, B),
-            "value": value,
+            "value": agg["value"],
             "unit": "env steps/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": agg["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
+            "timed_blocks": blocks,
+            "per_rank_value": agg["per_rank_value"],
             "config": {"workload": "configs[2]: board_size=%d, batch=%d/GPU random rollouts, auto-reset, "
                                    "step-granular (state in HBM between launches)" % (n, B),
                        "board_size": n, "batch_per_gpu": B, "seed": args.seed,
-                       "prologue_steps": args.prologue, "sharding": "contiguous board ids, no collectives",
-                       "result_hist_rank0": hist},
+                       "prologue_steps": args.prologue,
+                       "sharding": "rank r owns board ids [r*B,(r+1)*B) on GPU r; no collective on the data path "
+                                   "or in the timed region (gloo barriers around it)",
+                       "first_board_ids": [r["first_board_id"] for r in sorted(per_rank, key=lambda r: r["rank"])],
+                       "timing": "%d block(s) of exactly %d launches, each between two device synchronisations; "
+                                 "value = all env steps / slowest rank's summed block time" % (blocks, K),
+                       "result_hist_rank0": hist, "dry_run": bool(args.dry_run)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "moved_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                         "basis": ("bytes moved per launch by PMC (traffic) / kernel time" if traffic is not None else
+                                   "design byte model x boards / kernel time (no PMC measurement of this build and "
+                                   "workload is committed: traffic is null)"),
+                         "traffic_source": traffic_src,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                         "kernel": ("step_kernel64_small<%d, false>" if 2 * ((n * n + 31) // 32) + 3 <= 25
-                                    else "step_kernel64<%d, false>") % n,
+                         "kernel": ("step_kernel64_small<%d, false>" if small else "step_kernel64<%d, false>") % n,
                          "kernel_ms": kernel_ms,
+                         "design_model_bytes_per_env_step": db,
+                         "traffic_over_design_model": (traffic / B / db) if traffic is not None else None,
                          "algorithmic_bytes_per_env_step": ab,
-                         "note": "achieved = %d B x env steps / kernel time (SURVEY 8(d) model: full state "
-                                 "read + write per step).  The log-structured state rewrites the planes only "
-                                 "every 8th launch, so the kernel moves fewer bytes per env step than that (traffic, PMC: "
-                                 "%s) and the algorithmic figure can exceed the HBM peak."
-                                 % (ab, ("%.0f B per env step" % (traffic / B)) if traffic else "not collected for this "
-                                    "board size")},
+                         "algorithmic_equivalent_GBps": ab * B / (kernel_ms * 1e-3) / 1e9,
+                         "note": "frac = bytes really moved / kernel time / 8 TB/s, so it cannot exceed 1.  "
+                                 "algorithmic_equivalent_GBps prices the same launches at SURVEY 8(d)'s %d B per env "
+                                 "step (full state read + write); the log-structured state moves fewer bytes than "
+                                 "that, so this model figure may exceed the peak and is NOT a utilisation." % ab},
         }
-        if world == 1 and not args.no_rollout:
+        if env is not None and world == 1 and not args.no_observation:
+            out["observation"] = observation_rate(env, min(B, 1 << 17))
+        if env is not None and world == 1 and not args.no_rollout:
             out["fused_rollout"] = fused_rollout(env, args.seed)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(n, args.seed)
         print(json.dumps(out), flush=True)
-    env.close()
-    if world > 1:
+    if env is not None:
+        env.close()
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

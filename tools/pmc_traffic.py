@@ -48,7 +48,12 @@ def main():
         out[name] = sum(v for _, v in rows) / len(rows)
     fetch = 2.0 * out["FETCH_SIZE"] * 1024.0
     write = out["WRITE_SIZE"] * 1024.0
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from twixt_for_open_spiel_amd import build as bld
     js = {
+        # what the measurement is valid for: bench.py reports it only for this build and workload
+        "source_stamp": bld.source_stamp(), "lib_sha256": bld.lib_stamp(), "board_size": n, "batch": b,
+        "knobs": sorted(k for k in os.environ if k.startswith("TWX_")),
         "FETCH_SIZE_KB_per_launch_mean": out["FETCH_SIZE"],
         "WRITE_SIZE_KB_per_launch_mean": out["WRITE_SIZE"],
         "kernel": tag,
@@ -61,6 +66,7 @@ def main():
         "hbm_bytes_per_launch": fetch + write,
         "hbm_bytes_per_env_step": (fetch + write) / b,
     }
+    js["hbm_GBps_note"] = "divide hbm_bytes_per_launch by the kernel's average duration in *_kernel_stats.csv"
     with open(prefix + "_traffic.json", "w") as fh:
         json.dump(js, fh, indent=1)
     print(json.dumps(js))

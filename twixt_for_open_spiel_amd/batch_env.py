@@ -115,12 +115,14 @@ class TwixtBatchEnv:
         _lib.check(self.lib.twx_status_boards(self._h, _ptr(t), n, _ptr(res), _ptr(mc), _ptr(cp), self._stream()))
         return res, mc, cp
 
-    # TwixTState::ObservationTensor (twixt.cc:101-132)
-    def observation(self, ids=None):
+    # TwixTState::ObservationTensor (twixt.cc:101-132); `count`: the first `count` boards
+    def observation(self, ids=None, count=None, out=None):
         t = self._ids(ids)
-        m = self.batch if t is None else t.numel()
+        m = (self.batch if count is None else int(count)) if t is None else t.numel()
         n = self.board_size
-        out = torch.empty((m, 12, n, n - 2), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((m, 12, n, n - 2), dtype=torch.float32, device=self.device)
+        assert out.numel() == m * 12 * n * (n - 2) and out.dtype == torch.float32 and out.is_contiguous()
         _lib.check(self.lib.twx_observation_boards(self._h, _ptr(t), m, _ptr(out), self._stream()))
         return out
 

@@ -17,14 +17,38 @@ def hipcc():
     return "hipcc"
 
 
+# keep the ticket draw of the dynamic batch order a plain asynchronous atomic: the atomic
+# optimizer would turn it into a wave reduction that waits for the result at once
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+
+
+def source_stamp():
+    """sha256 over everything the library is built from (sources in name order + flags).
+    Measurements that are only valid for one binary (profiles/*traffic*.json) carry it."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def lib_stamp():
+    """sha256 of the built libtwixt_hip.so (None if it is not built)."""
+    import hashlib
+    if not os.path.exists(LIB):
+        return None
+    with open(LIB, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     """Compile if the library is missing or older than its sources.  Returns the path."""
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # keep the ticket draw of the dynamic batch order a plain asynchronous atomic: the
-           # atomic optimizer would turn it into a wave reduction that waits for the result at once
-           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", LIB, SRC]
+    cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
