@@ -285,7 +285,7 @@ def test_full_size_every_board(torch_mod):
         hist += np.bincount(ref["planes"][:, sw - 3] & 3, minlength=4)
     res, _, _ = env.status()
     assert np.array_equal(torch.bincount(res.to(torch.int64), minlength=4).cpu().numpy(), hist)
-    assert total > 0.95 * batch * steps   # nearly every launch steps every board (auto-reset)
+    assert total == batch * steps   # auto-reset: every launch is exactly one env step on every board
     env.close()
 
 
