@@ -81,7 +81,8 @@ typedef struct twx_env twx_env; /* opaque: owns the device state of B boards */
 /* Board::Board(int,bool) x batch (tb.cc:168-174) + TwixTGame range check
  * (tw.cc:139-144).  Allocates B boards on HIP device `device`, all in the
  * initial position.  `first_board_id` is the global id of board 0 (the batch
- * shard offset on multi-GPU runs; it only feeds the random policy's hash). */
+ * shard offset on multi-GPU runs; it only feeds the random policy's hash).  Board ids
+ * are 32-bit policy keys: first_board_id + batch > 2^32 is refused with TWX_E_ARG. */
 int twx_create(int board_size, int64_t batch, int device, uint64_t first_board_id, twx_env **out);
 int twx_destroy(twx_env *env);
 
@@ -123,8 +124,10 @@ int twx_step_random_boards(twx_env *env, const int32_t *ids_dev, int64_t n, uint
  * with LegalActions + ApplyAction in a loop): every board (ids_dev == NULL, n = 0 or B) or
  * every listed board plays the random policy of twx_step_random, without auto-reset, until
  * it is terminal or max_steps moves were made; the state stays on chip between moves.
- * Identical to max_steps calls of twx_step_random(auto_reset = 0).  status_dev[n or B] gets
- * the final status byte (may be NULL). */
+ * The boards end up exactly as after max_steps calls of twx_step_random(auto_reset = 0).
+ * status_dev[n or B] (may be NULL) gets result | TWX_ST_SWAPPED, plus TWX_ST_NOOP for a board
+ * that was already terminal when the call began (it made no move); the byte of a board never
+ * depends on the other boards of the call. */
 int twx_random_rollout(twx_env *env, const int32_t *ids_dev, int64_t n, uint32_t seed, int max_steps,
                        uint8_t *status_dev, void *stream);
 

@@ -58,6 +58,9 @@ def test_argument_errors_without_a_device():
     assert lib.twx_create(8, 0, 0, 0, C.byref(h)) == E_ARG and b"batch" in lib.twx_last_error()
     assert lib.twx_create(8, -5, 0, 0, C.byref(h)) == E_ARG
     assert lib.twx_create(8, 4, 0, 0, None) == E_ARG
+    # board ids are 32-bit policy keys: a shard that would wrap is refused, not aliased
+    assert lib.twx_create(8, 4, 0, 1 << 32, C.byref(h)) == E_ARG and b"2^32" in lib.twx_last_error()
+    assert lib.twx_create(8, 4, 0, (1 << 32) - 3, C.byref(h)) == E_ARG
     lib.twx_destroy(None)  # a no-op
     calls = [
         lambda: lib.twx_reset(None, None),

@@ -403,7 +403,12 @@ def test_fused_rollout(torch_mod, n, batch):
     ref = ob.rollout_batch(n, seed, 40, batch, maxlen + 5, False, want_cells=True, want_trace=True)
     compare_planes(env, ref["planes"], what="rollout")
     assert np.array_equal(env.export_cells().cpu().numpy(), ref["cells"])
-    assert np.array_equal(st & 3, ref["planes"][:, -3] & 3) and (st & 3).all()  # every game finished
+    sc = ref["planes"][:, -3]
+    want_st = (sc & 3) | (((sc >> 8) & 1) << 5)         # result | TWX_ST_SWAPPED: every board made a move
+    assert np.array_equal(st, want_st.astype(np.uint8)) and (st & 3).all()  # the whole byte; every game finished
+    again = env.random_rollout(seed).cpu().numpy()      # terminal on entry: untouched, NOOP on every board
+    assert np.array_equal(again, (want_st | 0x40).astype(np.uint8))
+    compare_planes(env, ref["planes"], what="second rollout")
     # bounded rollout of a subset from the initial position
     env.reset()
     ids = np.arange(3, batch, 7, dtype=np.int32)

@@ -89,8 +89,77 @@ def _build_cpp_driver(out):
     return out
 
 
+def _build_cpu_search(out):
+    """The same driver source with the CPU oracle behind the evaluator interface
+    (tests/mcts_cpu_evaluator.h): 'the CPU engine doing the same search' of SURVEY 8(f3)."""
+    import os
+    import subprocess
+    import oracle_binding as ob
+    ob.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                           "-DMCTS_EVALUATOR_HEADER=\"mcts_cpu_evaluator.h\"", "-I" + os.path.join(root, "include"),
+                           "-I/opt/rocm/include", "-I" + os.path.join(root, "tests"), "-I" + os.path.join(root, "oracle"),
+                           os.path.join(root, "twixt_for_open_spiel_amd", "spiel_adapter", "mcts_driver.cc"), "-o", out,
+                           "-L" + os.path.join(root, "oracle"), "-ltwixt_oracle",
+                           "-Wl,-rpath," + os.path.join(root, "oracle")])
+    return out
+
+
+MOVE_PAT = r"move (\d+): player (\d) plays (\d+) \((\d+) visits\)"
+
+
+def _run_driver(exe, args, timeout=900):
+    import re
+    import subprocess
+    out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    text = out.stdout.decode()
+    rate = float(re.search(r"= (\d+) simulations/s", text).group(1))
+    return re.findall(MOVE_PAT, text), rate, text
+
+
 def test_cpp_driver_compiles(tmp_path):
     _build_cpp_driver(str(tmp_path / "mcts_driver"))
+
+
+def test_cpu_search_equals_python_oracle_search(tmp_path, capsys):
+    """CPU: mcts_driver.cc over the oracle evaluator header plays the game mcts.py plays over
+    the Python OracleEvaluator (same moves, same visit counts) -- this pins the header the
+    full-size GPU test and tools/mcts_bench.py compare the device search with."""
+    import re
+    from twixt_for_open_spiel_amd.mcts import self_play
+    exe = _build_cpu_search(str(tmp_path / "mcts_cpu"))
+    cpp_lines, _, _ = _run_driver(exe, [8, 640, 6, 128, 3])
+    capsys.readouterr()
+    hist, _, _ = self_play(8, max_simulations=640, leaves_per_batch=128, max_moves=6, seed=3,
+                           evaluator=OracleEvaluator(8, 128), verbose=True)
+    py_lines = re.findall(MOVE_PAT, capsys.readouterr().out)
+    assert cpp_lines == py_lines and [int(m[2]) for m in cpp_lines] == hist and len(hist) == 6
+
+
+@pytest.mark.gpu
+def test_config5_full_size(tmp_path, capsys):
+    """BASELINE config 5 at its stated size: board_size=12, max_simulations=20000 per move, 2,048
+    leaves per device round trip, two moves of self-play (README.md:36-42's mcts_example run).
+    The device-driven C++ search, the same C++ search on the CPU oracle and mcts.py over the
+    Python OracleEvaluator choose the same moves with the same visit counts; both C++ rates are
+    printed (pytest -s) and recorded by tools/mcts_bench.py."""
+    import re
+    from twixt_for_open_spiel_amd.mcts import self_play
+    dev_exe = _build_cpp_driver(str(tmp_path / "mcts_driver"))
+    cpu_exe = _build_cpu_search(str(tmp_path / "mcts_cpu"))
+    args = [12, 20000, 2, 2048, 1]
+    dev_lines, dev_rate, _ = _run_driver(dev_exe, args)
+    cpu_lines, cpu_rate, _ = _run_driver(cpu_exe, args)
+    assert len(dev_lines) == 2 and dev_lines == cpu_lines
+    capsys.readouterr()
+    hist, _, total = self_play(12, max_simulations=20000, leaves_per_batch=2048, max_moves=2, seed=1,
+                               evaluator=OracleEvaluator(12, 2048), verbose=True)
+    py_lines = re.findall(MOVE_PAT, capsys.readouterr().out)
+    assert total == 40000 and py_lines == dev_lines
+    print("config 5 (N=12, 20000 simulations/move, 2048 leaves/batch): device search %.0f simulations/s, "
+          "CPU search (oracle, all host cores) %.0f simulations/s" % (dev_rate, cpu_rate))
 
 
 @pytest.mark.gpu

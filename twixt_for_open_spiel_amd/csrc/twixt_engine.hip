@@ -53,7 +53,7 @@ int fail(int code, const std::string &msg) {
 #endif
 #include "twixt_device_common.h"
 #include "twixt_step_kernel.h"
-#ifdef TWX_ENABLE_WINDOW
+#ifdef TWX_ENABLE_WINDOW  // experiment, not in the product tree: build with -Itools/experiments
 #include "twixt_window_kernel.h"
 #endif
 #include "twixt_util_kernels.h"
@@ -380,6 +380,10 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   if (n < TWX_MIN_BOARD_SIZE || n > TWX_MAX_BOARD_SIZE)  // tw.cc:139-144
     return fail(TWX_E_SIZE, "board_size out of range [5..24]: " + std::to_string(n));
   if (batch <= 0) return fail(TWX_E_ARG, "twx_create: batch must be positive");
+  // global board ids are 32-bit keys of the policy hash (twixt_geom.h policy_hash): a shard whose
+  // ids would wrap is refused rather than silently aliased onto other boards' trajectories
+  if (first_board_id > 0xffffffffull || first_board_id + (uint64_t)batch > 0x100000000ull)
+    return fail(TWX_E_ARG, "twx_create: first_board_id + batch must not exceed 2^32 (board ids are 32-bit policy keys)");
   DeviceGuard device_guard_(device);
   HIP_TRY(device_guard_.err);
   int cus = 0;

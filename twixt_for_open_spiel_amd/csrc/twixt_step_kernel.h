@@ -157,7 +157,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   STAMP(1);  // LDS fill + prefetch issue
 #ifdef TWX_SKELETON
   prefetch(kPf1, NJ);
-  const bool was_reset = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
+  const bool was_reset = false, terminal_on_entry = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
   { uint32_t *const sk = lds + (bl << 2) + 2 * G::W * RS; sk[0] += 1u; }
 #else
   uint32_t *const me = lds + (bl << 2);  // this board's slot inside every chunk row
@@ -211,6 +211,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   wave_sync();
 
   STAMP(2);  // reset / journal replay
+  const bool terminal_on_entry = result != 0u;  // (after the auto-reset, if any)
   int a = -1;
   bool act = false, illegal = false;
   uint32_t dirty = 0u;
@@ -534,7 +535,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       uint8_t st = (uint8_t)(result | (swapped << 5));
       if (illegal) st |= TWX_ST_ILLEGAL;
       if (was_reset) st |= TWX_ST_RESET;
-      if (random && !act) st |= TWX_ST_NOOP;
+      // a play-out (rsteps > 1) reports NOOP only for a board that was terminal when it began:
+      // the byte must not depend on when the OTHER boards of the wave finished
+      if (random && (rsteps > 1 ? terminal_on_entry : !act)) st |= TWX_ST_NOOP;
       status[row] = st;
     }
     if (actions_out) actions_out[row] = a;

@@ -105,6 +105,12 @@ struct Timer {
   ~Timer() { g_t[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// The evaluator can be swapped at build time: tests/mcts_cpu_evaluator.h plugs the CPU checker
+// in behind the same interface, so that the identical search can be timed and compared on the
+// host (tests/test_mcts.py, tools/mcts_bench.py).  The product build has no such header.
+#ifdef MCTS_EVALUATOR_HEADER
+#include MCTS_EVALUATOR_HEADER
+#else
 // slots 0..L-1 are scratch leaves, slots L..L+G-1 the roots of the G games (mcts.py: DeviceEvaluator)
 class Device {
  public:
@@ -209,6 +215,7 @@ class Device {
   int8_t *d_cp_;
   uint32_t *d_mask_;
 };
+#endif  // MCTS_EVALUATOR_HEADER
 
 static void Returns(int result, double r[2]) {  // twixt.h:50-63
   r[0] = result == 1 ? 1.0 : result == 2 ? -1.0 : 0.0;

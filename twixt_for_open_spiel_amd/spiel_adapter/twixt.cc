@@ -45,11 +45,32 @@ void Hip(hipError_t e) {
   if (e != hipSuccess) SpielFatalError(std::string("twixt_hip: ") + hipGetErrorString(e));
 }
 
+// the pool's scratch buffers live on the pool's device, whatever the caller's current one is
+class OnDevice {
+ public:
+  explicit OnDevice(int device) {
+    Hip(hipGetDevice(&prev_));
+    if (prev_ != device) {
+      Hip(hipSetDevice(device));
+      changed_ = true;
+    }
+  }
+  ~OnDevice() {
+    if (changed_) (void)hipSetDevice(prev_);
+  }
+
+ private:
+  int prev_ = 0;
+  bool changed_ = false;
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------- DeviceBoards
-DeviceBoards::DeviceBoards(int board_size, int capacity) : n_(board_size), capacity_(capacity) {
-  Twx(twx_create(board_size, capacity, /*device=*/0, /*first_board_id=*/0, &env_));
+DeviceBoards::DeviceBoards(int board_size, int capacity, int device)
+    : n_(board_size), capacity_(capacity), device_(device) {
+  OnDevice guard(device_);
+  Twx(twx_create(board_size, capacity, device_, /*first_board_id=*/0, &env_));
   mask_words_ = twx_mask_words(board_size);
   free_.reserve(capacity);
   for (int i = capacity - 1; i >= 0; --i) free_.push_back(i);
@@ -63,6 +84,7 @@ DeviceBoards::DeviceBoards(int board_size, int capacity) : n_(board_size), capac
 }
 
 DeviceBoards::~DeviceBoards() {
+  OnDevice guard(device_);
   for (void *p : {d_ids_, d_ids2_, d_action_, d_status_, d_mask_, d_obs_, d_cells_})
     if (p) (void)hipFree(p);
   twx_destroy(env_);
@@ -71,6 +93,8 @@ DeviceBoards::~DeviceBoards() {
 void DeviceBoards::PutId(void *dst, int32_t slot) { Hip(hipMemcpy(dst, &slot, 4, hipMemcpyHostToDevice)); }
 
 int32_t DeviceBoards::Acquire() {
+  std::lock_guard<std::mutex> lock(mu_);
+  OnDevice guard(device_);
   if (free_.empty())
     SpielFatalError("twixt: out of device board slots (raise TWX_ADAPTER_SLOTS, now " +
                     std::to_string(capacity_) + ")");
@@ -81,9 +105,14 @@ int32_t DeviceBoards::Acquire() {
   return slot;
 }
 
-void DeviceBoards::Release(int32_t slot) { free_.push_back(slot); }
+void DeviceBoards::Release(int32_t slot) {
+  std::lock_guard<std::mutex> lock(mu_);
+  free_.push_back(slot);
+}
 
 void DeviceBoards::Copy(int32_t dst, int32_t src) {
+  std::lock_guard<std::mutex> lock(mu_);
+  OnDevice guard(device_);
   PutId(d_ids_, dst);
   PutId(d_ids2_, src);
   Twx(twx_copy_boards(env_, static_cast<const int32_t *>(d_ids_), env_, static_cast<const int32_t *>(d_ids2_), 1,
@@ -91,6 +120,8 @@ void DeviceBoards::Copy(int32_t dst, int32_t src) {
 }
 
 uint8_t DeviceBoards::Step(int32_t slot, Action action) {
+  std::lock_guard<std::mutex> lock(mu_);
+  OnDevice guard(device_);
   PutId(d_ids_, slot);
   // an action outside int32 can never be legal: any out-of-range value reports "illegal"
   const int32_t a = (action < 0 || action > 0x7fffffff) ? -1 : static_cast<int32_t>(action);
@@ -103,6 +134,8 @@ uint8_t DeviceBoards::Step(int32_t slot, Action action) {
 }
 
 std::vector<Action> DeviceBoards::LegalActions(int32_t slot) {
+  std::lock_guard<std::mutex> lock(mu_);
+  OnDevice guard(device_);
   PutId(d_ids_, slot);
   Twx(twx_legal_mask_boards(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<uint32_t *>(d_mask_),
                             nullptr, nullptr));
@@ -115,12 +148,16 @@ std::vector<Action> DeviceBoards::LegalActions(int32_t slot) {
 }
 
 void DeviceBoards::Observation(int32_t slot, float *out) {
+  std::lock_guard<std::mutex> lock(mu_);
+  OnDevice guard(device_);
   PutId(d_ids_, slot);
   Twx(twx_observation_boards(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<float *>(d_obs_), nullptr));
   Hip(hipMemcpy(out, d_obs_, sizeof(float) * kNumPlanes * n_ * (n_ - 2), hipMemcpyDeviceToHost));
 }
 
 std::string DeviceBoards::ToString(int32_t slot, bool ansi, bool swapped, int result) {
+  std::lock_guard<std::mutex> lock(mu_);
+  OnDevice guard(device_);
   PutId(d_ids_, slot);
   Twx(twx_export_cells(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<uint8_t *>(d_cells_), nullptr));
   std::vector<uint8_t> cells(4 * n_ * n_);
@@ -153,9 +190,14 @@ TwixTState::TwixTState(const TwixTState &other)
 TwixTState::~TwixTState() { boards_->Release(slot_); }
 
 std::string TwixTState::ActionToString(Player player, Action action) const {
-  char buf[16];
-  twx_action_to_string(boards_->board_size(), player, action, buf, sizeof buf);
-  return buf;
+  char buf[16] = {0};
+  const int n = boards_->board_size();
+  if (twx_action_to_string(n, player, action, buf, sizeof buf) >= 0) return buf;
+  // outside [0, N*N): the reference formats whatever position the id decodes to (tw.cc:67-74)
+  std::string s = (player == kRedPlayer) ? "x" : "o";
+  s += static_cast<char>(static_cast<int>('a') + static_cast<int>(action / n));
+  s.append(std::to_string(n - static_cast<int>(action % n)));
+  return s;
 }
 
 std::string TwixTState::ToString() const {
@@ -215,11 +257,12 @@ TwixTGame::TwixTGame(const GameParameters &params)
 }
 
 std::shared_ptr<DeviceBoards> TwixTGame::boards() const {
-  if (!boards_) {
+  std::call_once(boards_once_, [this] {
     const char *v = std::getenv("TWX_ADAPTER_SLOTS");
     const int capacity = (v && std::atoi(v) > 0) ? std::atoi(v) : 4096;
-    boards_ = std::make_shared<DeviceBoards>(board_size_, capacity);
-  }
+    const char *d = std::getenv("TWX_ADAPTER_DEVICE");
+    boards_ = std::make_shared<DeviceBoards>(board_size_, capacity, d ? std::atoi(d) : 0);
+  });
   return boards_;
 }
 

@@ -12,6 +12,7 @@
 #define OPEN_SPIEL_GAMES_TWIXT_TWIXT_H_
 
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,9 +29,14 @@ inline constexpr int kMinBoardSize = 5, kMaxBoardSize = 24, kDefaultBoardSize = 
 inline constexpr bool kDefaultAnsiColorOutput = true;  // twixtboard.h:36
 
 // Pool of board slots inside one twx_env, shared by all states of a game object.
+// Threading: open_spiel's MCTS and evaluators clone and use States from several threads.  The
+// pool has ONE set of scratch buffers and a twx_env is used by one thread at a time
+// (include/twixt_hip.h), so every method takes the pool's mutex: States of one game may be
+// used from any thread, their device calls are serialised.  The pool lives on HIP device
+// TWX_ADAPTER_DEVICE (default 0) and holds TWX_ADAPTER_SLOTS live states (default 4096).
 class DeviceBoards {
  public:
-  DeviceBoards(int board_size, int capacity);
+  DeviceBoards(int board_size, int capacity, int device = 0);
   ~DeviceBoards();
   DeviceBoards(const DeviceBoards &) = delete;
   DeviceBoards &operator=(const DeviceBoards &) = delete;
@@ -45,7 +51,8 @@ class DeviceBoards {
   int board_size() const { return n_; }
 
  private:
-  int n_, capacity_, mask_words_;
+  int n_, capacity_, device_, mask_words_;
+  std::mutex mu_;
   twx_env *env_ = nullptr;
   std::vector<int32_t> free_;
   void *d_ids_ = nullptr, *d_ids2_ = nullptr, *d_action_ = nullptr, *d_status_ = nullptr, *d_mask_ = nullptr,
@@ -107,6 +114,7 @@ class TwixTGame : public Game {
  private:
   bool ansi_color_output_;
   int board_size_;
+  mutable std::once_flag boards_once_;
   mutable std::shared_ptr<DeviceBoards> boards_;
 };
 
