@@ -106,6 +106,54 @@ __host__ __device__ __forceinline__ long chunk_index(long c, long b, long bpad, 
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Tile I/O of the whole-batch step kernel (tiled layout, 64 boards per wave): the 64 boards of a
+// batch are ONE contiguous block of CHT KiB, chunk c at byte c*1024 + lane*16.  Written as
+// instructions, not as C++ loads, for two reasons:
+//   * addressing: one scalar tile base + a handful of constant per-lane offsets + the 13-bit
+//     immediate (chunks of 8: offset c%8 * 1024 - 4096) instead of a 64-bit address per chunk
+//     (the generic form cost ~80 SGPRs -- the kernel spilled 49 -- and ~250 scalar instructions
+//     per batch);
+//   * registers: the prefetched batch (CHT x 16 B per lane) lives in AGPRs for the whole step.
+//     global_load writes AGPRs and ds_write reads them directly on gfx950 (one register file);
+//     left to the compiler, the loads landed in VGPRs and were copied to AGPRs and back
+//     (156 v_accvgpr moves per batch) behind an s_waitcnt in the MIDDLE of the step -- i.e. the
+//     wave waited for its prefetch long before it needed it.
+// The compiler does not see these loads: the kernel waits for them explicitly (vm_wait_all)
+// before the LDS fill, and nothing may copy the registers in between (checked in the ISA: no
+// v_accvgpr_* in the kernel).  Untracked younger loads only make the compiler's own counted
+// waits stricter, never weaker (vmcnt counts in order).
+// ---------------------------------------------------------------------------
+constexpr int kChunksPerOffset = 8;  // chunks one per-lane offset register reaches through the immediate
+template <int J, bool AG>
+__device__ __forceinline__ void tile_load_chunk(u32x4 &dst, uint32_t voff, const void *tile) {
+  if constexpr (AG)
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
+                 "n"((J % kChunksPerOffset) * 1024 - 4096) : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(tile),
+                 "n"((J % kChunksPerOffset) * 1024 - 4096) : "memory");
+}
+template <int C0, int C1, bool AG>
+__device__ __forceinline__ void tile_load(u32x4 *nxt, const uint32_t *voff, const void *tile) {
+  if constexpr (C0 < C1) {
+    tile_load_chunk<C0, AG>(nxt[C0], voff[C0 / kChunksPerOffset], tile);
+    tile_load<C0 + 1, C1, AG>(nxt, voff, tile);
+  }
+}
+// LDS image row c of this lane: byte lds_lane + c*1024 (16-bit immediate)
+template <int C0, int C1, bool AG>
+__device__ __forceinline__ void tile_fill(uint32_t lds_lane, const u32x4 *nxt) {
+  if constexpr (C0 < C1) {
+    if constexpr (AG)
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lds_lane), "a"(nxt[C0]), "n"(C0 * 1024) : "memory");
+    else
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lds_lane), "v"(nxt[C0]), "n"(C0 * 1024) : "memory");
+    tile_fill<C0 + 1, C1, AG>(lds_lane, nxt);
+  }
+}
+__device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush = 8, kFlagReverse = 16,
               kFlagRolling = 32,  // + bits 8..11: journal period, bits 12..27: batch stride of a wave
               kFlagDynamic = 64;  // batches after a wave's first are drawn from the ticket counters

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/twixt_hip.h"

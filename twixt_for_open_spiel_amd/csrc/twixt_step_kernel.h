@@ -14,6 +14,14 @@
 // (kFlagCompact) writes everything and clears the journal.  Lanes that
 // auto-reset write their whole board; lanes whose flood fill changed flag
 // words write those chunks.
+// Diagnostic builds only (-DTWX_ABLATE=mask, tools/README.md): leave a phase out to measure what
+// it really costs inside the overlapped loop (results are then wrong by construction).
+//   1 flood fill   2 dirty-chunk stores   4 journal replay   8 apply   16 every store   32 LDS fill
+#ifndef TWX_ABLATE
+#define TWX_ABLATE 0
+#endif
+constexpr int kAblate = TWX_ABLATE;
+
 template <int N, bool SUB, int BPW>
 __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, long batch,
                                                      const int32_t *__restrict__ actions,
@@ -38,6 +46,11 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
                 oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
   constexpr uint32_t kColMask = (1u << N) - 1u;
   static_assert(CHT == 2 * W + 1 + twx::kJournalChunks && W <= 32, "layout");
+  // whole-batch launches on the tiled layout address a batch as one contiguous tile and keep
+  // the prefetched batch in AGPRs (big boards: one wave per SIMD owns all 512 registers)
+  constexpr bool FAST = !SUB && BPW == 64 && TWX_TILED != 0;
+  constexpr bool AG = FAST && CHT > TWX_SMALL_CHT;
+  constexpr int NG = (CHT + kChunksPerOffset - 1) / kChunksPerOffset;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
 
@@ -98,7 +111,24 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   };
   long round = 0;  // batches this wave has begun
   uint32_t tv = (dyn && nstatic == 1) ? draw() : 0u;
-  {
+  // FAST: byte offset of this lane's 16 bytes inside chunk 8g+4 of a tile (g = 0..NG-1), and the
+  // tile of batch idx (scalar).  lds_lane: LDS byte address of this lane's slot in chunk row 0.
+  uint32_t voff[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    voff[g] = (uint32_t)lane * 16u + (uint32_t)g * (kChunksPerOffset * 1024u) + 4096u;
+    asm volatile("" : "+v"(voff[g]));  // stays a register: not re-derived per load
+  }
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const uint32_t lds_lane = (uint32_t)(uintptr_t)((lds_u32 *)lds) + (uint32_t)lane * 16u;
+  auto tile_of = [&](long i) -> char * {
+    const long t = (flags & kFlagReverse) ? (nbatch - 1 - i) : i;
+    return reinterpret_cast<char *>(state) + t * (long)(CHT * 1024);
+  };
+  if constexpr (FAST) {
+    tile_load<0, CHT, AG>(nxt, voff, tile_of(idx));
+    vm_wait_all();  // first batch: nothing to overlap with
+  } else {
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
@@ -131,32 +161,49 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   const long board_raw = row_board(row);
   const bool inb = (unsigned long)board_raw < (unsigned long)batch;
   const long board = (ids && !inb) ? 0L : board_raw;  // padding lanes of a subset load board 0
-  const bool wr = !ids || inb;  // subset mode: padding lanes must not store
+  const bool wr = (!ids || inb) && !(kAblate & 16);  // subset mode: padding lanes must not store
   const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
+  if constexpr ((kAblate & 32) != 0) {
+  } else if constexpr (FAST) {
+    tile_fill<0, CHT, AG>(lds_lane, nxt);
+  } else {
 #pragma unroll
-  for (int j = 0; j < NJ; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
+    for (int j = 0; j < NJ; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
+  }
   wave_sync();
   // prefetch of the next batch, issued in three slices between the phases below so
   // that the wave never sits behind a 39-deep burst in its memory-issue queue (the
   // last iteration harmlessly re-reads its own batch)
   long b1 = batch_board((idx_next < nbatch) ? idx_next : idx);
   if (ids && (unsigned long)b1 >= (unsigned long)batch) b1 = 0;
-  auto prefetch = [&](int c0, int c1) {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, bpad, CHT)];
-    __builtin_amdgcn_sched_barrier(0);
-  };
+  const char *const tile_next = tile_of((idx_next < nbatch) ? idx_next : idx);
 #ifndef TWX_PF_A
 #define TWX_PF_A 4
 #define TWX_PF_B 8
 #endif
   constexpr int kPf1 = NJ * TWX_PF_A / 12, kPf2 = NJ * TWX_PF_B / 12;  // slice boundaries
-  prefetch(0, kPf1);
+  // slice 0: chunks [0, kPf1), slice 1: [kPf1, kPf2), slice 2: [kPf2, NJ)
+  auto prefetch = [&](auto slice) {
+    constexpr int sl = decltype(slice)::value;
+    constexpr int c0 = sl == 0 ? 0 : sl == 1 ? kPf1 : kPf2, c1 = sl == 0 ? kPf1 : sl == 1 ? kPf2 : NJ;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FAST) {
+      tile_load<c0, c1, AG>(nxt, voff, tile_next);
+    } else {
+#pragma unroll
+      for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, bpad, CHT)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Slice0 = std::integral_constant<int, 0>;
+  using Slice1 = std::integral_constant<int, 1>;
+  using Slice2 = std::integral_constant<int, 2>;
+  prefetch(Slice0{});
 
   STAMP(1);  // LDS fill + prefetch issue
 #ifdef TWX_SKELETON
-  prefetch(kPf1, NJ);
+  prefetch(Slice1{});
+  prefetch(Slice2{});
   const bool was_reset = false, terminal_on_entry = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
   { uint32_t *const sk = lds + (bl << 2) + 2 * G::W * RS; sk[0] += 1u; }
 #else
@@ -187,7 +234,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     // ---- replay the redo journal: slots 0..jpos-1 in order, branch-free ORs ----
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-      if (s < jpos) {  // wave-uniform
+      if (s < jpos && !(kAblate & 4)) {  // wave-uniform
         const uint32_t e = jn[(s >> 2) * RS + (s & 3)];
         const int cell = (int)(e & 1023u);
         const uint32_t bit = (e & twx::kJValid) ? (1u << (cell & 31)) : 0u;  // empty record: every OR is a no-op
@@ -218,7 +265,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // rsteps == 1: one env step.  rsteps > 1 (twx_random_rollout): up to rsteps moves per
   // board with the state staying in LDS, until every board of the batch is terminal.
   for (int rs = 0; rs < rsteps; rs++) {
-  if (rs == 0) prefetch(kPf1, kPf2);
+  if (rs == 0) prefetch(Slice1{});
   const int player = (int)(counter & 1u);
   const bool open = (result == 0u);
 
@@ -279,7 +326,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
 
   STAMP(4);  // action select
-  if (rs == 0) prefetch(kPf2, NJ);
+  if (rs == 0) prefetch(Slice2{});
+  if (kAblate & 8) act = false;
   int pa = 0;          // cell the peg finally lands on
   uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
   uint32_t entry = 0;  // journal record of this move
@@ -415,6 +463,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   //      op each), rows by bit shifts; stop when no half found a new cell. ----
   uint64_t todo = __ballot(pend != 0u);
   if (BPW == 32) todo &= 0xffffffffull;  // the upper half mirrors the lower one
+  if (kAblate & 1) todo = 0ull;
   while (todo) {
     const int s0 = (int)__ffsll((unsigned long long)todo) - 1;
     todo &= todo - 1;
@@ -488,45 +537,56 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // The prefetched batch has had the whole step to arrive: retire its loads HERE, before
   // this batch's stores are issued, so that the wait at the top of the next iteration
   // does not also wait for those stores (loads and stores share one in-order counter).
+  if constexpr (FAST) {
+    vm_wait_all();
+  } else {
 #pragma unroll
-  for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));
+    for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));
+  }
   // (the draw is older than the prefetch, so it has returned as well)
   const long idx_after = drawn ? ticket_batch(tv) : (long)blockIdx.x + (round + 2) * gridDim.x;
 
   STAMP(7);  // wait for the prefetched batch
   // ---- stream back ----
   // (lane -> LDS row j*64+lane holds chunk chunk_of(j) of board bl: the fill's mapping)
+  char *const tile_cur = tile_of(idx);
+  auto chunk_ptr = [&](int c) -> uint4 * {  // where chunk c of this lane's board lives
+    if constexpr (FAST)
+      return reinterpret_cast<uint4 *>(tile_cur + ((uint32_t)lane * 16u + (uint32_t)c * 1024u));
+    else
+      return state + chunk_index(c, board, bpad, CHT);
+  };
   if (compact) {
 #pragma unroll
     for (int j = 0; j < NJ; j++)
-      if (wr && chunk_of(j) < CHT) state[chunk_index(chunk_of(j), board, bpad, CHT)] = lds4[j * kWave + lane];
+      if (wr && chunk_of(j) < CHT) *chunk_ptr(chunk_of(j)) = lds4[j * kWave + lane];
   } else {
     const int jc = CJ + (jpos >> 2);  // the journal chunk of slot jpos
     if (BPW == 64) {
       if (wr) {
-        state[chunk_index(CS, board, bpad, CHT)] = lds4[CS * kWave + lane];  // scalars
-        state[chunk_index(jc, board, bpad, CHT)] = lds4[jc * kWave + lane];
+        *chunk_ptr(CS) = lds4[CS * kWave + lane];  // scalars
+        *chunk_ptr(jc) = lds4[jc * kWave + lane];
       }
     } else {  // one store: lower half the scalars chunk, upper half the journal chunk
       const int c = half ? jc : CS;
-      if (wr) state[chunk_index(c, board, bpad, CHT)] = lds4[c * BPW + bl];
+      if (wr) *chunk_ptr(c) = lds4[c * BPW + bl];
     }
     STAMP(9);  // fixed stores (scalars + journal chunk)
     // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
     // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
-    uint32_t dd = (was_reset || !wr || half) ? 0u : dirty;
+    uint32_t dd = (was_reset || !wr || half || (kAblate & 2)) ? 0u : dirty;
     while (__ballot(dd != 0u)) {
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
         dd &= dd - 1;
-        state[chunk_index(c, board, bpad, CHT)] = lds4[c * BPW + bl];
+        *chunk_ptr(c) = lds4[c * BPW + bl];
       }
     }
     STAMP(10);  // dirty flag chunks
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && chunk_of(j) < CHT) state[chunk_index(chunk_of(j), board, bpad, CHT)] = lds4[j * kWave + lane];
+        if (was_reset && chunk_of(j) < CHT) *chunk_ptr(chunk_of(j)) = lds4[j * kWave + lane];
     }
   }
   STAMP(11);  // reset lanes / compaction
