@@ -4,7 +4,11 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import twixt_for_open_spiel_amd._lib as L
+if len(sys.argv) > 1:  # usage: launch_times.py [lib.so]   (TWX_* knobs from the environment)
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
 from twixt_for_open_spiel_amd import TwixtBatchEnv
+print(os.path.basename(L.LIB_PATH), " ".join("%s=%s" % kv for kv in sorted(os.environ.items()) if kv[0].startswith("TWX_")))
 env = TwixtBatchEnv(24, 1 << 20)
 for _ in range(720):
     env.step_random(1, True, want_actions=False, want_status=False)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Mean per launch of arbitrary rocprofv3 --pmc counters for the step kernel.
 usage: pmc_counters.py OUT.json DIR [DIR...] (each DIR: one `rocprofv3 --pmc A B C -d DIR -- python3
-bench.py --steps 64 --warmup 0 --no-cpu-baseline --no-rollout` pass); the last 64 launches count."""
+bench.py --steps 64 --warmup 0 --no-cpu-baseline --no-rollout` pass); the last 64 launches count.
+PMC_KERNEL=<substring of the kernel name> selects the kernel (default: whichever step kernel ran)."""
 import csv
 import glob
 import json
@@ -9,15 +10,18 @@ import os
 import sys
 
 out_path, dirs = sys.argv[1], sys.argv[2:]
-tag, k = "step_kernel64<24, false>", 64
+tag, k = os.environ.get("PMC_KERNEL", ""), 64
+TAGS = [tag] if tag else ["step_pair_kernel<24>", "step_kernel64<24, false>"]
 res = {}
 for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                if tag not in row["Kernel_Name"]:
+                hit = [t for t in TAGS if t in row["Kernel_Name"]]
+                if not hit:
                     continue
+                tag = hit[0]
                 key = (row["Counter_Name"], int(row["Dispatch_Id"]))
                 acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])
         for name in sorted({n for n, _ in acc}):

@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (first: the process must share ONE libamdhip64 with torch)
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libtwixt_hip.so")
+# (TWIXT_HIP_LIB: a diagnostic build of the same library, e.g. tools/bin/*.so -- tools/README.md)
+LIB_PATH = os.environ.get("TWIXT_HIP_LIB") or os.path.join(PKG, "libtwixt_hip.so")
 
 TWX_OK = 0
 ST_RESULT_MASK, ST_ILLEGAL, ST_RESET, ST_SWAPPED, ST_NOOP = 0x03, 0x04, 0x10, 0x20, 0x40

@@ -54,9 +54,7 @@ int fail(int code, const std::string &msg) {
 #endif
 #include "twixt_device_common.h"
 #include "twixt_step_kernel.h"
-#ifdef TWX_ENABLE_WINDOW  // experiment, not in the product tree: build with -Itools/experiments
-#include "twixt_window_kernel.h"
-#endif
+#include "twixt_pair_kernel.h"
 #include "twixt_util_kernels.h"
 
 template <int N>
@@ -78,11 +76,7 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
       if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
     }
   } else {
-#ifdef TWX_ENABLE_BPW32
-    if (ids) TWX_LAUNCH((step_kernel32<N, true>)); else TWX_LAUNCH((step_kernel32<N, false>));
-#else
     return hipErrorInvalidConfiguration;
-#endif
   }
 #undef TWX_LAUNCH
   return hipGetLastError();
@@ -101,46 +95,40 @@ int step_occupancy(int bpw) {
     else
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64<N, false>, kWave, lds_bytes);
   } else {
-#ifdef TWX_ENABLE_BPW32
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel32<N, false>, kWave, lds_bytes);
-#else
     e = hipErrorInvalidConfiguration;
-#endif
   }
   return (e == hipSuccess && blocks > 0) ? blocks : 0;
 }
 
-// windowed kernel: launch + occupancy (0 waves = this board size has no windowed variant)
+// two-lanes-per-board kernel (twixt_pair_kernel.h): whole-batch steps of the big boards
 template <int N>
-hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
-                         uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                         const uint4 *init_chunks, hipStream_t s) {
-#ifdef TWX_ENABLE_WINDOW
-  if constexpr (WinGeo<N>::kUsable && twx::Geo<N>::CHT > 20) {
-    const long nbatch = bpad / kWave;
+hipError_t launch_pair(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
+                       uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
+                       uint32_t *ticket, TicketBases ticket_base, int nstatic, hipStream_t s) {
+  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+    const long nbatch = bpad / 32;
     const long grid = nbatch < (long)waves ? nbatch : (long)waves;
-    hipLaunchKernelGGL((step_window_kernel<N>), dim3((unsigned)grid), dim3(kWave), WinGeo<N>::lds_bytes, s, state,
-                       bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, init_chunks);
+    const size_t lds_bytes = (size_t)(twx::Geo<N>::CHT + 1) / 2 * 2 * 32 * 16;  // 20 KiB at N=24
+    hipLaunchKernelGGL((step_pair_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch,
+                       actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
     return hipGetLastError();
   }
-#endif
   return hipErrorInvalidConfiguration;
 }
 template <int N>
-int window_occupancy() {
-#ifdef TWX_ENABLE_WINDOW
-  if constexpr (WinGeo<N>::kUsable && twx::Geo<N>::CHT > 20) {
+int pair_occupancy() {
+  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_kernel<N>, kWave, WinGeo<N>::lds_bytes) !=
-        hipSuccess)
+    const size_t lds_bytes = (size_t)(twx::Geo<N>::CHT + 1) / 2 * 2 * 32 * 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_pair_kernel<N>, kWave, lds_bytes) != hipSuccess)
       return 0;
     return blocks;
   }
-#endif
   return 0;
 }
-typedef hipError_t (*win_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t, int, int,
-                             int, const uint4 *, hipStream_t);
+typedef hipError_t (*pair_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t, int, int,
+                              int, uint32_t *, TicketBases, int, hipStream_t);
+
 typedef int (*wocc_fn)();
 
 typedef int (*occ_fn)(int);
@@ -149,25 +137,25 @@ typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, u
 
 template <int N>
 struct StepTable {
-  static void fill(step_fn *t, occ_fn *o, win_fn *w, wocc_fn *wo) {
+  static void fill(step_fn *t, occ_fn *o, pair_fn *p, wocc_fn *po) {
     t[N] = &launch_step<N>;
     o[N] = &step_occupancy<N>;
-    w[N] = &launch_window<N>;
-    wo[N] = &window_occupancy<N>;
-    StepTable<N - 1>::fill(t, o, w, wo);
+    p[N] = &launch_pair<N>;
+    po[N] = &pair_occupancy<N>;
+    StepTable<N - 1>::fill(t, o, p, po);
   }
 };
 template <>
 struct StepTable<TWX_MIN_BOARD_SIZE - 1> {
-  static void fill(step_fn *, occ_fn *, win_fn *, wocc_fn *) {}
+  static void fill(step_fn *, occ_fn *, pair_fn *, wocc_fn *) {}
 };
 
 struct StepTables {
   step_fn step[TWX_MAX_BOARD_SIZE + 1];
   occ_fn occ[TWX_MAX_BOARD_SIZE + 1];
-  win_fn win[TWX_MAX_BOARD_SIZE + 1];
-  wocc_fn wocc[TWX_MAX_BOARD_SIZE + 1];
-  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, win, wocc); }
+  pair_fn pair[TWX_MAX_BOARD_SIZE + 1];
+  wocc_fn pocc[TWX_MAX_BOARD_SIZE + 1];
+  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc); }
 };
 const StepTables &step_tables() {
   static const StepTables t;  // thread-safe static init
@@ -196,8 +184,8 @@ struct twx_env {
   int waves;  // persistent grid: resident waves = CUs x waves the LDS image admits per CU
   int bpw;    // boards per wave: 64 or 32 (TWX_BOARDS_PER_WAVE)
   int init_off;    // word offset of the initial-position chunks inside `tables`
-  bool window;     // use step_window_kernel for the non-compaction whole-batch launches
-  int waves_win;   // its persistent grid
+  bool pair;       // whole-batch launches go to step_pair_kernel (two lanes per board; big boards)
+  int waves_pair;  // its persistent grid
   // dynamic batch order (TWX_DYNAMIC): device ticket counters (never reset) and the values
   // they will have when the next launch starts
   bool dynamic;
@@ -270,15 +258,14 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   if ((whole_step || flush) && e->rolling && e->period > 1)
     flags |= kFlagRolling | (e->period << 8) | ((e->waves > 0xffff ? 0xffff : e->waves) << 12);
   if (e->pingpong && !ids && (e->launches & 1)) flags |= kFlagReverse;
-  if (e->window && whole_step && !(flags & (kFlagCompact | kFlagRolling))) {
-    HIP_TRY(step_tables().win[e->d.n](e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                                      (uint32_t)e->first_id, flags, jarg, e->waves_win,
-                                      reinterpret_cast<const uint4 *>(e->tables + e->init_off), s));
-  } else {
+  {
+    // whole-batch launches of the big boards: the two-lanes-per-board kernel
+    const bool use_pair = e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling);
+    const int bpw = use_pair ? 32 : e->bpw, waves = use_pair ? e->waves_pair : e->waves;
     // dynamic tail: the groups need equal numbers of waves, and there must be batches beyond
     // the first round; by default the last eighth of the rounds (at least two) is dynamic
-    const long nbatch = ids ? (nsub + e->bpw - 1) / e->bpw : e->d.bpad / e->bpw;
-    const long grid = nbatch < (long)e->waves ? nbatch : (long)e->waves;
+    const long nbatch = ids ? (nsub + bpw - 1) / bpw : e->d.bpad / bpw;
+    const long grid = nbatch < (long)waves ? nbatch : (long)waves;
     // ... and the draws must stay well below what a counter sustains (~75 M tickets/s): a
     // launch draws about 4 * grid / kTicketGroups tickets per counter in (nbatch / grid) batch
     // times of ~10 us, so the tail is dynamic only while grid^2 <= 300 * nbatch.  Measured at
@@ -290,9 +277,14 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     if (nstatic > rounds) nstatic = rounds;
     if (nstatic < 1) nstatic = 1;
     if (dyn) flags |= kFlagDynamic;
-    HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                             (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->bpw, e->ticket,
-                             e->ticket_base, (int)nstatic, s));
+    if (use_pair)
+      HIP_TRY(step_tables().pair[e->d.n](e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
+                                         (uint32_t)e->first_id, flags, jarg, waves, e->ticket, e->ticket_base,
+                                         (int)nstatic, s));
+    else
+      HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
+                               (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->bpw, e->ticket,
+                               e->ticket_base, (int)nstatic, s));
     if (dyn) {
       // group g: its dynamic batches (idx >= nstatic * grid, idx % groups == g) + two draws per
       // wave that come back past the end (wraps with the counter)
@@ -413,20 +405,16 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->ticket = nullptr;
   e->ticket_base = TicketBases{};
   {
-#ifdef TWX_ENABLE_BPW32
-    e->bpw = env_int("TWX_BOARDS_PER_WAVE", 64, 32, 64) >= 48 ? 64 : 32;
-#else
     e->bpw = 64;
-#endif
     // as many waves as are resident at once (LDS image and registers; 4 per CU at N=24,
     // 8 at N=12, 12 at N=8): each walks its share of the batches
     int per_cu = step_tables().occ[n](e->bpw);
     if (per_cu < 1) per_cu = 4;
     if (per_cu > 16) per_cu = 16;
     e->waves = (cus > 0 ? cus : 256) * env_int("TWX_WAVES_PER_CU", per_cu, 1, 32);
-    const int wocc = step_tables().wocc[n]();
-    e->window = wocc > 0 && e->bpw == 64 && e->period > 1 && !e->rolling && env_int("TWX_WINDOW", 0, 0, 1) != 0;
-    e->waves_win = (cus > 0 ? cus : 256) * env_int("TWX_WINDOW_WAVES_PER_CU", wocc > 0 ? wocc : 1, 1, 32);
+    const int pocc = step_tables().pocc[n]();
+    e->pair = pocc > 0 && e->bpw == 64 && env_int("TWX_PAIR", 1, 0, 1) != 0;
+    e->waves_pair = (cus > 0 ? cus : 256) * env_int("TWX_PAIR_WAVES_PER_CU", pocc > 0 ? pocc : 1, 1, 32);
   }
   e->d.batch = batch;
   e->d.bpad = (batch + kWave - 1) / kWave * kWave;

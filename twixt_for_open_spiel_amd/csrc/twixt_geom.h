@@ -42,9 +42,19 @@ constexpr int state_chunks(int n) { return state_words(n) / 4; }  // 16-byte chu
 constexpr int kJournalSlots = TWX_JOURNAL_SLOTS;  // a multiple of 4 (whole 16-byte chunks)
 constexpr int kJournalChunks = kJournalSlots / 4;
 constexpr int total_chunks(int n) { return state_chunks(n) + kJournalChunks; }
-// record: bit31 valid | cell[9:0] | player[10] | link mask[18:11] | gain START[19] |
-//         gain END[20] | swap[21]
+// record of one move: bit31 valid | cell[9:0] | player[10] | link mask[18:11] | gain START[19] |
+//   gain END[20] | swap[21] | result after the move[23:22] | single-cell fill: direction[26:24]
+//   of the linked neighbour that gains START[27] / END[28] (the flood-fill shortcut of the step
+//   kernels: what ExploreLocalGraph, tb.cc:573-588, does when it flags exactly one cell).
+// The scalars chunk is rewritten only together with the whole board (compaction, reset, subset /
+// roll-out launches); between two such writes the true scalars are the stored ones advanced by
+// the records, in slot order: journal_scalars().
 constexpr uint32_t kJValid = 0x80000000u;
+constexpr int kJResultShift = 22, kJFillDirShift = 24;
+constexpr uint32_t kJGainStart = 1u << 19, kJGainEnd = 1u << 20, kJSwap = 1u << 21, kJFillStart = 1u << 27,
+                   kJFillEnd = 1u << 28;
+// (dx + 2, dy + 2) of the 8 directions, 4 bits each: a direction held in a register -> its offset
+constexpr uint32_t kDxPack = 0x10013443u, kDyPack = 0x43100134u;
 
 constexpr bool is_corner(int n, int x, int y) {
   return (x == 0 || x == n - 1) && (y == 0 || y == n - 1);
@@ -159,6 +169,18 @@ TWX_HD inline uint32_t policy_hash(uint32_t seed, uint32_t board, uint32_t episo
   h *= 0x846ca68bu;
   h ^= h >> 16;
   return h;
+}
+
+// scalars after the move a journal record describes (move_counter, move_one, result, swapped:
+// tb.h:75-78 as Board::ApplyAction, tb.cc:457-499, leaves them); an empty record changes nothing
+TWX_HD inline void journal_scalars(uint32_t e, uint32_t &counter, uint32_t &move_one, uint32_t &result,
+                                   uint32_t &swapped) {
+  if (e & kJValid) {
+    if (counter == 0u) move_one = e & 1023u;  // tb.cc:485-488
+    counter += 1u;
+    result = (e >> kJResultShift) & 3u;
+    swapped |= (e >> 21) & 1u;
+  }
 }
 
 }  // namespace twx

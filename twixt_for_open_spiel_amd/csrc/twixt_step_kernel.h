@@ -17,6 +17,7 @@
 // Diagnostic builds only (-DTWX_ABLATE=mask, tools/README.md): leave a phase out to measure what
 // it really costs inside the overlapped loop (results are then wrong by construction).
 //   1 flood fill   2 dirty-chunk stores   4 journal replay   8 apply   16 every store   32 LDS fill
+//   64 (pair kernel) dirty-chunk loop runs but stores nothing
 #ifndef TWX_ABLATE
 #define TWX_ABLATE 0
 #endif
@@ -125,8 +126,13 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     const long t = (flags & kFlagReverse) ? (nbatch - 1 - i) : i;
     return reinterpret_cast<char *>(state) + t * (long)(CHT * 1024);
   };
+  // the second journal chunk (slots 4..7) is read only when a slot in it may hold a record:
+  // jpos > 4, or a launch that rewrites everything (its replay position may be anything under
+  // rolling compaction); otherwise its LDS row is zero-filled if slot 4 is about to be written
+  const bool need_j2 = twx::kJournalChunks != 2 || jpos_arg > 4 || (flags & (kFlagCompact | kFlagRolling)) != 0;
   if constexpr (FAST) {
-    tile_load<0, CHT, AG>(nxt, voff, tile_of(idx));
+    tile_load<0, CHT - 1, AG>(nxt, voff, tile_of(idx));
+    if (need_j2) tile_load<CHT - 1, CHT, AG>(nxt, voff, tile_of(idx));
     vm_wait_all();  // first batch: nothing to overlap with
   } else {
     long b0 = batch_board(idx);
@@ -165,7 +171,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
   if constexpr ((kAblate & 32) != 0) {
   } else if constexpr (FAST) {
-    tile_fill<0, CHT, AG>(lds_lane, nxt);
+    tile_fill<0, CHT - 1, AG>(lds_lane, nxt);
+    if (need_j2) tile_fill<CHT - 1, CHT, AG>(lds_lane, nxt);
+    else *reinterpret_cast<uint4 *>(lds + (bl << 2) + (CHT - 1) * RS) = make_uint4(0u, 0u, 0u, 0u);
   } else {
 #pragma unroll
     for (int j = 0; j < NJ; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
@@ -188,7 +196,12 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     constexpr int c0 = sl == 0 ? 0 : sl == 1 ? kPf1 : kPf2, c1 = sl == 0 ? kPf1 : sl == 1 ? kPf2 : NJ;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FAST) {
-      tile_load<c0, c1, AG>(nxt, voff, tile_next);
+      if constexpr (c1 == NJ) {
+        tile_load<c0, c1 - 1, AG>(nxt, voff, tile_next);
+        if (need_j2) tile_load<c1 - 1, c1, AG>(nxt, voff, tile_next);
+      } else {
+        tile_load<c0, c1, AG>(nxt, voff, tile_next);
+      }
     } else {
 #pragma unroll
       for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, bpad, CHT)];
@@ -217,6 +230,17 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   uint32_t result = sv.y & 0xffu, swapped = (sv.y >> 8) & 1u;
   uint32_t episode = sv.z;
   bool was_reset = false;
+  // The stored scalars are as old as the planes: advance them by the journal records first
+  // (slots 0..jpos-1, in order) -- the reset decision below needs the TRUE result.
+  uint32_t jr[twx::kJournalSlots];
+#pragma unroll
+  for (int k = 0; k < twx::kJournalChunks; k++) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(jn + k * RS);
+    jr[4 * k + 0] = q.x; jr[4 * k + 1] = q.y; jr[4 * k + 2] = q.z; jr[4 * k + 3] = q.w;
+  }
+#pragma unroll
+  for (int s = 0; s < twx::kJournalSlots - 1; s++)
+    if (s < jpos && !(kAblate & 4)) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
 
   if (random && (flags & kFlagAutoReset) && result != 0u && inb) {
     // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in place ----
@@ -235,7 +259,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++) {
       if (s < jpos && !(kAblate & 4)) {  // wave-uniform
-        const uint32_t e = jn[(s >> 2) * RS + (s & 3)];
+        const uint32_t e = jr[s];  // (move_one is final already: it is set by move 0 and a swap is move 1)
         const int cell = (int)(e & 1023u);
         const uint32_t bit = (e & twx::kJValid) ? (1u << (cell & 31)) : 0u;  // empty record: every OR is a no-op
         uint32_t *const g = me + (cell >> 5) * GS;
@@ -252,6 +276,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
         }
         lds_or(g + oS, (e & (1u << 19)) ? bit : 0u);
         lds_or(g + oE, (e & (1u << 20)) ? bit : 0u);
+        {  // the single neighbour a fill flagged (the record carries its direction)
+          const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
+          const bool on = (e & (twx::kJFillStart | twx::kJFillEnd)) != 0u;
+          const int t = on ? cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2 : cell;
+          uint32_t *const gt = me + (t >> 5) * GS;
+          lds_or(gt + oS, (e & twx::kJFillStart) ? (1u << (t & 31)) : 0u);
+          lds_or(gt + oE, (e & twx::kJFillEnd) ? (1u << (t & 31)) : 0u);
+        }
       }
     }
   }
@@ -331,7 +363,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   int pa = 0;          // cell the peg finally lands on
   uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
   uint32_t entry = 0;  // journal record of this move
-  uint32_t fast_dirty = 0;  // flag chunk touched by the single-cell fill shortcut
+  uint32_t fill1 = 0;  // single-cell fill of the shortcut below, as record bits
   if (act) {
     // ---- Board::ApplyAction (tb.cc:457-499) ----
     pa = a;
@@ -396,8 +428,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     if (want && !(neutral & (neutral - 1u)) && (!(want & 1u) || (linkm & ~ts) == neutral) &&
         (!(want & 2u) || (linkm & ~te) == neutral)) {
       const int d = __ffs((int)neutral) - 1;
-      constexpr uint32_t kDxPack = 0x10013443u, kDyPack = 0x43100134u;  // (offset + 2) per direction, 4 bits each
-      const int tx = x + (int)((kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((kDyPack >> (4 * d)) & 15u) - 2;
+      const int tx = x + (int)((twx::kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((twx::kDyPack >> (4 * d)) & 15u) - 2;
       const int t = tx * N + ty;
       uint32_t *const gt = me + (t >> 5) * GS;
       uint32_t other = (gt[plane_off(2)] | gt[plane_off(3)] | gt[plane_off(4)] | gt[plane_off(5)]) >> (t & 31);
@@ -413,7 +444,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
         const uint32_t tbit = 1u << (t & 31);
         lds_or(gt + oS, (want & 1u) ? tbit : 0u);
         lds_or(gt + oE, (want & 2u) ? tbit : 0u);
-        fast_dirty = 1u << (t >> 5);
+        // persisted by this move's journal record (or by the whole-board write of this launch)
+        fill1 = ((uint32_t)d << twx::kJFillDirShift) | ((want & 1u) ? twx::kJFillStart : 0u) |
+                ((want & 2u) ? twx::kJFillEnd : 0u);
         want = 0u;
       }
     }
@@ -431,9 +464,6 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       }
       lds_or(g + oS, gain_s ? bit : 0u);
       lds_or(g + oE, gain_e ? bit : 0u);
-      entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
-              (gain_s ? 1u << 19 : 0u) | (gain_e ? 1u << 20 : 0u) | (swapnow ? 1u << 21 : 0u);
-
       if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
       counter += 1u;
       // ---- UpdateResult (tb.cc:192-207) ----
@@ -443,11 +473,18 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
         const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
         if (cnt_opp - (in_opp ? 1 : 0) == 0) result = 3u;
       }
+      entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
+              (gain_s ? twx::kJGainStart : 0u) | (gain_e ? twx::kJGainEnd : 0u) | (swapnow ? twx::kJSwap : 0u) |
+              (result << twx::kJResultShift) | fill1;
     }
   }
   STAMP(5);  // apply: windows, crossing test, links, result
   // s3 is used below as the board's dirty mask (bit i: flag words of group i changed)
-  *reinterpret_cast<uint4 *>(sc) = make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
+  // (a board that was reset in a journalling launch is written whole with the scalars of the
+  // EMPTY board: its first move is in the record, and stored scalars + records = the truth)
+  *reinterpret_cast<uint4 *>(sc) = (was_reset && !compact)
+                                       ? make_uint4(0u, 0u, episode, 0u)
+                                       : make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
   if (compact) {
 #pragma unroll
     for (int k = 0; k < twx::kJournalChunks; k++) *reinterpret_cast<uint4 *>(jn + k * RS) = make_uint4(0u, 0u, 0u, 0u);
@@ -527,7 +564,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
   wave_sync();
   STAMP(6);  // flood fill
-  dirty |= sc[3] | fast_dirty;
+  dirty |= sc[3];
   sc[3] = 0u;
   wave_sync();
   if (rs + 1 < rsteps && __ballot(inb && result == 0u) == 0ull) break;  // everyone finished
@@ -559,19 +596,12 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   if (compact) {
 #pragma unroll
     for (int j = 0; j < NJ; j++)
-      if (wr && chunk_of(j) < CHT) *chunk_ptr(chunk_of(j)) = lds4[j * kWave + lane];
+      if (wr && chunk_of(j) < CHT) tile_store(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
   } else {
-    const int jc = CJ + (jpos >> 2);  // the journal chunk of slot jpos
-    if (BPW == 64) {
-      if (wr) {
-        *chunk_ptr(CS) = lds4[CS * kWave + lane];  // scalars
-        *chunk_ptr(jc) = lds4[jc * kWave + lane];
-      }
-    } else {  // one store: lower half the scalars chunk, upper half the journal chunk
-      const int c = half ? jc : CS;
-      if (wr) *chunk_ptr(c) = lds4[c * BPW + bl];
-    }
-    STAMP(9);  // fixed stores (scalars + journal chunk)
+    // the journal chunk of slot jpos: all a step normally writes (the record carries the scalars)
+    const int jc = CJ + (jpos >> 2);
+    if (wr && half == 0) tile_store(chunk_ptr(jc), lds4[jc * BPW + bl]);
+    STAMP(9);  // fixed store (journal chunk)
     // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
     // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
     uint32_t dd = (was_reset || !wr || half || (kAblate & 2)) ? 0u : dirty;
@@ -579,14 +609,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
         dd &= dd - 1;
-        *chunk_ptr(c) = lds4[c * BPW + bl];
+        tile_store(chunk_ptr(c), lds4[c * BPW + bl]);
       }
     }
     STAMP(10);  // dirty flag chunks
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && chunk_of(j) < CHT) *chunk_ptr(chunk_of(j)) = lds4[j * kWave + lane];
+        if (was_reset && chunk_of(j) < CHT) tile_store(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
     }
   }
   STAMP(11);  // reset lanes / compaction
@@ -638,21 +668,5 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TWX_SMALL
   step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
                         rsteps, ticket, tbase, nstatic);
 }
-
-// 32 boards per wave: 20 KiB LDS image, 8 waves per CU (two per SIMD, 256 registers each).
-// Experiment (-DTWX_ENABLE_BPW32, TWX_BOARDS_PER_WAVE=32): bit-exact, but 15 % slower than
-// the 64-board kernel on MI355X (the duplicated per-board work doubles the issue demand
-// and the 256-register budget spills), so it is not built by default.
-#ifdef TWX_ENABLE_BPW32
-template <int N, bool SUB>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_kernel32(
-    uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
-    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
-    TicketBases tbase, int nstatic) {
-  step_body<N, SUB, 32>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                        rsteps, ticket, tbase, nstatic);
-}
-#endif
 
 #endif  // TWIXT_STEP_KERNEL_H_

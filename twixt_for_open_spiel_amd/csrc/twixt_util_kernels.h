@@ -116,7 +116,15 @@ __global__ void status_kernel(const uint4 *state, Dims d, const int32_t *ids, lo
   const long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) return;
   const uint4 s = state[chunk_index((d.CH - 1), b, d.bpad, d.CHT)];
-  const uint32_t counter = s.x & 0xffffu, res = s.y & 0xffu;
+  uint32_t counter = s.x & 0xffffu, res = s.y & 0xffu, move_one = s.x >> 16, swapped = (s.y >> 8) & 1u;
+  // the stored scalars are as old as the planes: advance them by the journal (empty slots are zero)
+  for (int k = 0; k < twx::kJournalChunks; k++) {
+    const uint4 jr = state[chunk_index(d.CH + k, b, d.bpad, d.CHT)];
+    twx::journal_scalars(jr.x, counter, move_one, res, swapped);
+    twx::journal_scalars(jr.y, counter, move_one, res, swapped);
+    twx::journal_scalars(jr.z, counter, move_one, res, swapped);
+    twx::journal_scalars(jr.w, counter, move_one, res, swapped);
+  }
   if (result) result[j] = (uint8_t)res;
   if (move_counter) move_counter[j] = (int32_t)counter;
   if (current_player) current_player[j] = res ? (int8_t)-4 : (int8_t)(counter & 1u);  // tw.h:99-103
