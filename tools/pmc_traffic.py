@@ -35,7 +35,10 @@ def main():
     k = int(sys.argv[4]) if len(sys.argv) > 4 else 64
     n = int(sys.argv[5]) if len(sys.argv) > 5 else 24
     b = int(sys.argv[6]) if len(sys.argv) > 6 else 1 << 20
-    tag = "step_kernel64<%d, false>" % n
+    # whichever whole-batch step kernel the library runs at this board size
+    tags = ["step_pair_kernel<%d>" % n, "step_kernel64<%d, false>" % n, "step_kernel64_small<%d, false>" % n]
+    tag = os.environ.get("PMC_KERNEL") or next(
+        (t for t in tags if per_dispatch(fetch_dir, "FETCH_SIZE", t)), tags[0])
     out = {}
     for name, directory in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
         rows = per_dispatch(directory, name, tag)[-k:]  # the timed launches come last

@@ -26,6 +26,9 @@
 // Reference lines: Board::ApplyAction tb.cc:457-499, SetPegAndLinks tb.cc:501-571, UpdateResult
 // tb.cc:192-207, LegalActions / DoApplyAction tw.h:86-104, Board::Board tb.cc:168-276.
 
+#ifndef TWX_FLOOD_REP
+#define TWX_FLOOD_REP 2
+#endif
 #ifndef TWX_STORE_EARLY
 #define TWX_STORE_EARLY 0
 #endif
@@ -39,6 +42,9 @@ __device__ __forceinline__ PairVal pair_swap(uint32_t v) {
   const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   return PairVal{r[0], r[1]};
 }
+
+// bit `pos` of v as a mask: 0 or -1 (v_bfe_i32)
+__device__ __forceinline__ int32_t sbit(uint32_t v, int pos) { return ((int32_t)(v << (31 - pos))) >> 31; }
 
 template <int N>
 __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long bpad, long batch,
@@ -132,6 +138,13 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   const int wsh = up ? 16 : 0;            // their byte positions in a crossing window
   const int sgn = up ? 1 : -1;            // side of the knight neighbours this lane looks at
   const int dflip = up ? 0 : 7;           // direction numbering: lower lane d = 7 - (upper lane's d)
+  // links of a move this lane writes: d = 2h, 2h+1 (west end = the new peg) and 4+2h, 5+2h (west end =
+  // the target, dlt cells away); their planes are the two at link_lo
+  const int own_sh = 11 + 2 * h;          // record bit of link 2h
+  const int dlt0 = up ? twx::kDX[6] * N + twx::kDY[6] : twx::kDX[4] * N + twx::kDY[4];
+  const int dlt1 = up ? twx::kDX[7] * N + twx::kDY[7] : twx::kDX[5] * N + twx::kDY[5];
+  const int offA = up ? oS : oR;          // first flag / peg word of a record's own cell
+  const uint32_t pm = up ? 0u : 1u;       // (the lower lane adds the player: red / blue words are adjacent)
   uint32_t *const me = lds + (bl << 2);   // this board's slot inside every chunk row
   uint32_t *const meh = me + (up ? WH * GS : 0);  // first word group of this lane's half
   uint32_t *const sc = me + CS * RS;      // scalars
@@ -188,31 +201,40 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       }
       wave_sync();
     }
-    // ---- replay the redo journal: slots 0..jpos-1 in order, branch-free; 7 LDS updates per
-    //      record, each issued by one lane of the pair (a reset board reads empty records) ----
+    // ---- replay the redo journal: slots 0..jpos-1 in order.  Work of one record, split over the
+    //      pair: lower lane the peg, links 0, 1 (west end = this cell) and 4, 5 (west end = the
+    //      target), the single-cell fill's START; upper lane START / END gained, links 2, 3 and
+    //      6, 7, the fill's END.  Both lanes' link planes are the two at link_lo, and every
+    //      condition is a sign-extended record bit ANDed into the value: no selects.
+    //      (a reset board reads empty records) ----
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++) {
       if (s < jpos && !(kAblate & 4)) {  // wave-uniform
         const uint32_t e = jr[s];  // (move_one is final already: it is set by move 0 and a swap is move 1)
         const int cell = (int)(e & 1023u);
-        const uint32_t bit = (e & twx::kJValid) ? (1u << (cell & 31)) : 0u;
+        const uint32_t bit = (1u << (cell & 31)) & (uint32_t)((int32_t)e >> 31);  // empty record: every OR is a no-op
         uint32_t *const g = me + (cell >> 5) * GS;
-        // lower: undo red's first peg on a swap (tb.cc:450-455); upper: nothing
-        lds_and(me + (move_one >> 5) * GS + oR, ((e & (1u << 21)) && !up) ? ~(1u << (move_one & 31)) : 0xffffffffu);
+        if (__ballot((e & twx::kJSwap) != 0u))  // rare: undo red's first peg on a swap (tb.cc:450-455)
+          lds_and(me + (move_one >> 5) * GS + oR, (e & twx::kJSwap) ? ~(1u << (move_one & 31)) : 0xffffffffu);
         // lower: the peg (red / blue words are adjacent); upper: START gained
-        lds_or(g + (up ? oS : oR + (int)((e >> 10) & 1u)), (!up || (e & (1u << 19))) ? bit : 0u);
-        lds_or(g + oE, (up && (e & (1u << 20))) ? bit : 0u);  // upper: END gained
+        lds_or(g + offA + (int)((e >> 10) & pm), bit & ((uint32_t)sbit(e, 19) | ~hm));
+        lds_or(g + oE, bit & (uint32_t)sbit(e, 20) & hm);  // upper: END gained
+        const uint32_t eo = e >> own_sh;  // bits 0, 1: this lane's links at the cell; bits 4, 5: at the targets
 #pragma unroll
-        for (int k = 0; k < 4; k++) {  // lower: links k whose west end is this peg; upper: links k+4, west end at the target
-          const bool on = ((e >> (11 + k)) >> (up ? 4 : 0)) & 1u;
-          const int tc = cell + ((on && up) ? twx::kDX[k + 4] * N + twx::kDY[k + 4] : 0);
-          lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + k), on ? (1u << (tc & 31)) : 0u);
+        for (int j = 0; j < 2; j++) lds_or(g + link_lo + j, bit & (uint32_t)sbit(eo, j));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint32_t on = (uint32_t)sbit(eo, 4 + j);
+          const int tc = cell + (int)((uint32_t)(j ? dlt1 : dlt0) & on);
+          lds_or(me + (tc >> 5) * GS + link_lo + j, (1u << (tc & 31)) & on);
         }
-        {  // the single neighbour a fill flagged: lower lane START, upper lane END
+        if (__ballot((e & (twx::kJFillStart | twx::kJFillEnd)) != 0u)) {
+          // the single neighbour a fill flagged: lower lane START, upper lane END
           const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
-          const bool on = (e & (up ? twx::kJFillEnd : twx::kJFillStart)) != 0u;
-          const int t = on ? cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2 : cell;
-          lds_or(me + (t >> 5) * GS + (up ? oE : oS), on ? (1u << (t & 31)) : 0u);
+          const int t = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
+          const uint32_t on = (uint32_t)sbit(e >> 27, h);
+          const int tt = on ? t : cell;  // (no fill: t is meaningless and may lie outside the board)
+          lds_or(me + (tt >> 5) * GS + (up ? oE : oS), (1u << (tt & 31)) & on);
         }
       }
     }
@@ -395,13 +417,16 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         }
       }
       pend = want;
-      {  // tb.cc:532-533: one stored bit per physical link, at its west end; lower lane links 0..3
-         // (west end = the new peg), upper lane links 4..7 (west end = the target)
+      {  // tb.cc:532-533: one stored bit per physical link, at its west end; lower lane links 0, 1
+         // (west end = the new peg) and 4, 5 (west end = the target), upper lane 2, 3 and 6, 7
+        const uint32_t lo = linkm >> (2 * h);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool on = ((linkm >> k) >> (up ? 4 : 0)) & 1u;
-          const int tc = pa + ((on && up) ? twx::kDX[k + 4] * N + twx::kDY[k + 4] : 0);
-          lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + k), on ? (1u << (tc & 31)) : 0u);
+        for (int j = 0; j < 2; j++) lds_or(gp + link_lo + j, pbit & (uint32_t)sbit(lo, j));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint32_t on = (uint32_t)sbit(lo, 4 + j);
+          const int tc = pa + (int)((uint32_t)(j ? dlt1 : dlt0) & on);
+          lds_or(me + (tc >> 5) * GS + link_lo + j, (1u << (tc & 31)) & on);
         }
         lds_or(gp + (up ? oE : oS), (up ? gain_e : gain_s) ? pbit : 0u);
         if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
@@ -470,7 +495,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         for (;;) {
           uint32_t fresh = 0u;
 #pragma unroll
-          for (int rep = 0; rep < 2; rep++) {  // two expansions per exit test
+          for (int rep = 0; rep < TWX_FLOOD_REP; rep++) {  // expansions per exit test
             // forward: a frontier cell with link e reaches (c+dx, y+dy); backward: cell (c,y) whose
             // link e ends in the frontier.  Columns move by DPP wave shifts, rows by bit shifts.
             const uint32_t a1 = ((front & lk[0]) << 2) | ((front & lk[3]) >> 2);
