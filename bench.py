@@ -35,20 +35,38 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                     # same guide: measured float4-copy ceiling
 MIN_TIMED_MS = 50.0                       # the K-step block is repeated until this much GPU time
 TRAFFIC_FILE = os.path.join("profiles", "traffic_step_kernel_n24.json")
-JOURNAL_PERIOD = 8                        # twixt_geom.h kJournalSlots: every 8th launch compacts
+
+
+def journal_period(n):
+    """twixt_engine.hip default_period(): launches between two whole-board writes."""
+    w = (n * n + 31) // 32
+    return 1 if w <= 2 else 2 if w == 3 else 4 if w <= 7 else 8
+
 
 
 def algo_bytes(n):
     return ALGO_BYTES.get(n, 2 * (9 * ((n * n + 7) // 8) + 8) + 8)
 
 
-def design_bytes(n):
-    """Bytes this design moves per env step by construction: every launch
-    reads the board's CHT = 2W+3 chunks of 16 B; 7 launches in 8 write the scalars chunk and one
-    journal chunk (32 B), the 8th rewrites all CHT chunks.  (Flag chunks a flood fill dirtied and
-    auto-reset boards add about 2 B.)"""
+def step_kernel_name(n):
+    """The kernel a whole-batch step launch runs at board size n (twixt_engine.hip run_step)."""
     cht = 2 * ((n * n + 31) // 32) + 3
-    return 16.0 * cht + ((JOURNAL_PERIOD - 1) * 32.0 + 16.0 * cht) / JOURNAL_PERIOD
+    if cht > 25:   # TWX_SMALL_CHT: N >= 19
+        return "step_pair_kernel<%d>" % n
+    return "step_kernel64_small<%d, false>" % n
+
+
+def design_bytes(n):
+    """Bytes this design moves per env step by construction, journal period
+    P = journal_period(n): every launch reads the board's CHT = 2W+3 chunks of 16 B (the big
+    boards' kernel skips the second journal chunk while it cannot hold a record: 5 launches in 8);
+    P-1 launches in P write one journal chunk (16 B: the record carries the scalars), the P-th
+    rewrites all CHT chunks.  (Flag chunks a multi-cell flood fill dirtied and auto-reset boards
+    add a few bytes.)"""
+    cht = 2 * ((n * n + 31) // 32) + 3
+    p = journal_period(n)
+    read = 16.0 * cht - (16.0 * 5 / 8 if cht > 25 else 0.0)
+    return read + ((p - 1) * 16.0 + 16.0 * cht) / p
 
 
 def host_cores():
@@ -364,7 +382,6 @@ def main(argv=None):
         traffic, traffic_src = (None, {"rejected": "dry run"}) if args.dry_run else measured_traffic(n, B)
         moved = traffic if traffic is not None else db * B  # bytes per launch the roofline is priced on
         achieved = moved / (kernel_ms * 1e-3) / 1e9
-        small = 2 * ((n * n + 31) // 32) + 3 <= 25
         out = {
             "metric": "env steps/sec at board_size=%d, batch=%d per GPU, random-action rollouts" % (n, B),
             "value": agg["value"],
@@ -398,7 +415,7 @@ def main(argv=None):
                          "traffic_source": traffic_src,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                         "kernel": ("step_kernel64_small<%d, false>" if small else "step_kernel64<%d, false>") % n,
+                         "kernel": step_kernel_name(n),
                          "kernel_ms": kernel_ms,
                          "design_model_bytes_per_env_step": db,
                          "traffic_over_design_model": (traffic / B / db) if traffic is not None else None,

@@ -29,7 +29,9 @@
  *     constant; meant for small, launch-bound batches such as search leaves);
  *     every other entry point first materialises the journal and is unaffected.
  *   - tuning knobs read once by twx_create from the environment: TWX_JOURNAL_PERIOD
- *     (1..8, default 8; 1 = rewrite the planes every step), TWX_PINGPONG (0/1, default 1:
+ *     (1..8; default by board size: 1 for N <= 8, 2 for N = 9, 4 for N = 10..14, 8 above;
+ *     1 = rewrite the planes every step), TWX_PAIR (0/1, default 1: whole-batch steps of
+ *     N >= 19 run the two-lanes-per-board kernel), TWX_PINGPONG (0/1, default 1:
  *     alternate the batch order between launches), TWX_WAVES_PER_CU (default: occupancy),
  *     TWX_DYNAMIC (0/1, default 1: the last rounds of a launch are handed out by ticket
  *     counters instead of a fixed wave -> batch map; like the journal position, the ticket

@@ -125,7 +125,8 @@ def test_roofline_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
 
 def test_design_byte_model():
     import bench
-    assert bench.design_bytes(24) == 624 + (7 * 32 + 624) / 8 == 730.0
+    assert bench.design_bytes(24) == (624 - 10) + (7 * 16 + 624) / 8 == 706.0
+    assert bench.step_kernel_name(24) == "step_pair_kernel<24>" and "small" in bench.step_kernel_name(12)
     assert bench.algo_bytes(24) == 1320 and bench.algo_bytes(12) == 348 and bench.algo_bytes(8) == 168
 
 

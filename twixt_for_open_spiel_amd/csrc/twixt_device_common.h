@@ -174,22 +174,18 @@ __device__ __forceinline__ void pair_tile_fill(uint32_t lds_lane, const u32x4 *n
     pair_tile_fill<C0 + 1, C1>(lds_lane, nxt);
   }
 }
-// Write-back of board chunks.  Non-temporal stores measured 2.2 % faster than plain ones on the
-// whole step (write-through sc0 sc1: 0.8 %): the written lines are not read again before the next
-// launch.  TWX_STORE_MODE: 0 plain, 1 nt (default), 2 sc0 sc1.
-#ifndef TWX_STORE_MODE
-#define TWX_STORE_MODE 1
-#endif
+// Write-back of board chunks.  Where the step is bound by the board stream (N >= 17) non-temporal
+// stores measured 2.2 % faster than plain ones on the whole step (write-through sc0 sc1: 0.8 %):
+// the written lines are not read again before the next launch.  The small boards are bound by
+// their integer work and ran 2-4 % faster with plain stores.
+template <bool NT>
 __device__ __forceinline__ void tile_store(uint4 *p, uint4 v) {
-#if TWX_STORE_MODE == 1
-  __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
-  __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
-#elif TWX_STORE_MODE == 2
-  const u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
-#else
-  *p = v;
-#endif
+  if constexpr (NT) {
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+  } else {
+    *p = v;
+  }
 }
 __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

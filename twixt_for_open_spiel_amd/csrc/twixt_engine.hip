@@ -52,6 +52,10 @@ int fail(int code, const std::string &msg) {
 #ifndef TWX_SMALL_CHT
 #define TWX_SMALL_CHT 25  // N <= 18: measured +19 % (N=17), +7 % (N=18); -3 % / -6 % at N=19 / 20
 #endif
+// board sizes whose state is at most this many chunks (N <= 16) write back with plain stores
+#ifndef TWX_PLAIN_STORE_CHT
+#define TWX_PLAIN_STORE_CHT 19
+#endif
 #include "twixt_device_common.h"
 #include "twixt_step_kernel.h"
 #include "twixt_pair_kernel.h"
@@ -195,6 +199,16 @@ struct twx_env {
 };
 
 namespace {
+
+// Journal period by board size (launches between two whole-board writes; measured at B = 2^20,
+// tools/sweep_small.sh): the journal trades write bytes for replay work, which pays where the
+// board stream is the bound.  N <= 8 (bound by the integer work, 112 B of state) rewrite the planes
+// every step, N = 9 every second, N = 10..14 every fourth, larger boards every eighth step.
+int default_period(int n) {
+  const int W = twx::plane_words(n);
+  const int p = W <= 2 ? 1 : W == 3 ? 2 : W <= 7 ? 4 : 8;
+  return p < twx::kJournalSlots ? p : twx::kJournalSlots;
+}
 
 int env_int(const char *name, int dflt, int lo, int hi) {
   const char *v = getenv(name);
@@ -391,7 +405,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->d.CH = twx::state_chunks(n);
   e->d.CHT = twx::total_chunks(n);
   e->jpos = 0;
-  e->period = env_int("TWX_JOURNAL_PERIOD", twx::kJournalSlots, 1, twx::kJournalSlots);
+  e->period = env_int("TWX_JOURNAL_PERIOD", default_period(n), 1, twx::kJournalSlots);
   e->pingpong = env_int("TWX_PINGPONG", 1, 0, 1) != 0;
   e->rolling = env_int("TWX_ROLLING", 0, 0, 1) != 0;  // measured 10 % slower than compacting all at once
   e->journal_live = false;

@@ -545,11 +545,11 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     if (compact) {
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (wr && 2 * j + h < CHT) tile_store(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
+        if (wr && 2 * j + h < CHT) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
     } else {
       {  // the journal chunk of slot jpos: all a step normally writes (the record carries the scalars)
         const int c = CJ + (jpos >> 2);
-        if (wr && !up) tile_store(chunk_ptr(c), lds4[c * BPW + bl]);
+        if (wr && !up) tile_store<true>(chunk_ptr(c), lds4[c * BPW + bl]);
       }
       // flag chunks a flood fill changed
       uint32_t dd = (was_reset || !wr || (kAblate & 2)) ? 0u : dirty;
@@ -569,7 +569,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
           const uint32_t mine = up ? d1 : ds;
           if (mine && grp) {
             const int c = 2 * (__ffs((int)mine) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
-            tile_store(chunk_ptr(c), lds4[c * BPW + bl]);
+            tile_store<true>(chunk_ptr(c), lds4[c * BPW + bl]);
           }
           ds = d1 & (d1 - 1u);
         }
@@ -582,7 +582,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         const uint32_t mine = up ? d1 : dd;
         if (mine) {
           const int c = 2 * (__ffs((int)mine) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
-          if (!(kAblate & 64)) tile_store(chunk_ptr(c), lds4[c * BPW + bl]);
+          if (!(kAblate & 64)) tile_store<true>(chunk_ptr(c), lds4[c * BPW + bl]);
           else { const uint32_t keep = lds[(c * BPW + bl) * 4]; asm volatile("" ::"v"(keep)); }
         }
         dd = d1 & (d1 - 1u);
@@ -591,7 +591,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
         for (int j = 0; j < NJ; j++)
-          if (was_reset && wr && 2 * j + h < CHT) tile_store(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
+          if (was_reset && wr && 2 * j + h < CHT) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
       }
     }
 #if TWX_STORE_EARLY  // experiment: the wait for the prefetch also covers the stores just issued

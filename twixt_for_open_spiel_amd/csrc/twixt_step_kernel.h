@@ -51,6 +51,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // the prefetched batch in AGPRs (big boards: one wave per SIMD owns all 512 registers)
   constexpr bool FAST = !SUB && BPW == 64 && TWX_TILED != 0;
   constexpr bool AG = FAST && CHT > TWX_SMALL_CHT;
+  constexpr bool NT = CHT > TWX_PLAIN_STORE_CHT;  // non-temporal write-back where the board stream is the bound
   constexpr int NG = (CHT + kChunksPerOffset - 1) / kChunksPerOffset;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
@@ -596,11 +597,11 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   if (compact) {
 #pragma unroll
     for (int j = 0; j < NJ; j++)
-      if (wr && chunk_of(j) < CHT) tile_store(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
+      if (wr && chunk_of(j) < CHT) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
   } else {
     // the journal chunk of slot jpos: all a step normally writes (the record carries the scalars)
     const int jc = CJ + (jpos >> 2);
-    if (wr && half == 0) tile_store(chunk_ptr(jc), lds4[jc * BPW + bl]);
+    if (wr && half == 0) tile_store<NT>(chunk_ptr(jc), lds4[jc * BPW + bl]);
     STAMP(9);  // fixed store (journal chunk)
     // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
     // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
@@ -609,14 +610,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
         dd &= dd - 1;
-        tile_store(chunk_ptr(c), lds4[c * BPW + bl]);
+        tile_store<NT>(chunk_ptr(c), lds4[c * BPW + bl]);
       }
     }
     STAMP(10);  // dirty flag chunks
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && chunk_of(j) < CHT) tile_store(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
+        if (was_reset && chunk_of(j) < CHT) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
     }
   }
   STAMP(11);  // reset lanes / compaction
