@@ -88,30 +88,23 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_FLUSH
 #endif
 
-// Where chunk c (16 bytes) of board b lives in the state array, in uint4 units.
-//   TWX_TILED=1: tiles of 64 boards, [tile][chunk][64] -- the 64 boards a wave works on are
-//     one contiguous CHT KiB block, whole DRAM pages per wave;
-//   TWX_TILED=0: rows, [chunk][board] -- a wave's CHT loads are 1 KiB each, bpad*16 bytes apart.
-// Either way the 64 lanes of a wave read 1 KiB contiguous per chunk.
-#ifndef TWX_TILED
-#define TWX_TILED 1
-#endif
-__host__ __device__ __forceinline__ long chunk_index(long c, long b, long bpad, int cht) {
-#if TWX_TILED
-  (void)bpad;
-  return ((b >> 6) * cht + c) * 64 + (b & 63);
-#else
-  (void)cht;
-  return c * bpad + b;
-#endif
+// Where chunk c (16 bytes) of board b lives in the state array, in uint4 units: tiles of 2^ts
+// boards, [tile][chunk][2^ts boards].  ts = 6 (64 boards, a wave of step_kernel64: one contiguous
+// CHT KiB block per wave, whole DRAM pages) for the boards up to N = 18; ts = 5 for N >= 19, whose
+// whole-batch kernel works on 32 boards per wave (twixt_pair_kernel.h): with 64-board tiles its
+// waves read interleaved 512-byte halves of every row and the bare read stream ran 6 % slower.
+constexpr int tile_shift(int cht) { return cht > TWX_SMALL_CHT ? 5 : 6; }
+__host__ __device__ __forceinline__ long chunk_index(long c, long b, int ts, int cht) {
+  return (((b >> ts) * cht + c) << ts) + (b & ((1L << ts) - 1));
 }
 
 // ---------------------------------------------------------------------------
-// Tile I/O of the whole-batch step kernel (tiled layout, 64 boards per wave): the 64 boards of a
-// batch are ONE contiguous block of CHT KiB, chunk c at byte c*1024 + lane*16.  Written as
+// Tile I/O of the whole-batch step kernel (64 boards per wave): the 64 boards of a batch are ONE
+// contiguous block of CHT KiB (one 64-board tile, or two 32-board tiles), chunk c of a tile at byte
+// c * RB + slot * 16 with RB = 16 << TS bytes per chunk row.  Written as
 // instructions, not as C++ loads, for two reasons:
 //   * addressing: one scalar tile base + a handful of constant per-lane offsets + the 13-bit
-//     immediate (chunks of 8: offset c%8 * 1024 - 4096) instead of a 64-bit address per chunk
+//     immediate (8 KiB per offset register: chunk c % (8192/RB) at c' * RB - 4096) instead of a 64-bit address per chunk
 //     (the generic form cost ~80 SGPRs -- the kernel spilled 49 -- and ~250 scalar instructions
 //     per batch);
 //   * registers: the prefetched batch (CHT x 16 B per lane) lives in AGPRs for the whole step.
@@ -124,21 +117,21 @@ __host__ __device__ __forceinline__ long chunk_index(long c, long b, long bpad, 
 // v_accvgpr_* in the kernel).  Untracked younger loads only make the compiler's own counted
 // waits stricter, never weaker (vmcnt counts in order).
 // ---------------------------------------------------------------------------
-constexpr int kChunksPerOffset = 8;  // chunks one per-lane offset register reaches through the immediate
-template <int J, bool AG>
+template <int J, bool AG, int TS>
 __device__ __forceinline__ void tile_load_chunk(u32x4 &dst, uint32_t voff, const void *tile) {
+  constexpr int RB = 16 << TS, CPO = 8192 / RB;
   if constexpr (AG)
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
-                 "n"((J % kChunksPerOffset) * 1024 - 4096) : "memory");
+                 "n"((J % CPO) * RB - 4096) : "memory");
   else
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(tile),
-                 "n"((J % kChunksPerOffset) * 1024 - 4096) : "memory");
+                 "n"((J % CPO) * RB - 4096) : "memory");
 }
-template <int C0, int C1, bool AG>
+template <int C0, int C1, bool AG, int TS>
 __device__ __forceinline__ void tile_load(u32x4 *nxt, const uint32_t *voff, const void *tile) {
   if constexpr (C0 < C1) {
-    tile_load_chunk<C0, AG>(nxt[C0], voff[C0 / kChunksPerOffset], tile);
-    tile_load<C0 + 1, C1, AG>(nxt, voff, tile);
+    tile_load_chunk<C0, AG, TS>(nxt[C0], voff[C0 / (8192 / (16 << TS))], tile);
+    tile_load<C0 + 1, C1, AG, TS>(nxt, voff, tile);
   }
 }
 // LDS image row c of this lane: byte lds_lane + c*1024 (16-bit immediate)
@@ -152,18 +145,19 @@ __device__ __forceinline__ void tile_fill(uint32_t lds_lane, const u32x4 *nxt) {
     tile_fill<C0 + 1, C1, AG>(lds_lane, nxt);
   }
 }
-// The same for step_pair_kernel (two lanes per board, 32 boards per wave): a lane moves chunks
-// 2j + half of its board; the per-lane offset registers already contain half * 1024, one register
-// reaches four even chunks (8 KiB); always AGPRs.  LDS image rows are 512 B (32 boards).
+// The same for step_pair_kernel (two lanes per board, 32 boards per wave, 32-board tiles): a lane
+// moves chunks 2j + half of its board; chunk pair j is the KiB at byte j * 1024 of the tile and the
+// per-lane offset registers already contain half * 512, so every instruction reads one contiguous
+// KiB; one register reaches eight pairs (8 KiB); always AGPRs.  LDS image rows are 512 B too.
 template <int J>
 __device__ __forceinline__ void pair_tile_load_chunk(u32x4 &dst, uint32_t voff, const void *tile) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
-               "n"((J % 4) * 2048 - 4096) : "memory");
+               "n"((J % 8) * 1024 - 4096) : "memory");
 }
 template <int C0, int C1>
 __device__ __forceinline__ void pair_tile_load(u32x4 *nxt, const uint32_t *voff, const void *tile) {
   if constexpr (C0 < C1) {
-    pair_tile_load_chunk<C0>(nxt[C0], voff[C0 / 4], tile);
+    pair_tile_load_chunk<C0>(nxt[C0], voff[C0 / 8], tile);
     pair_tile_load<C0 + 1, C1>(nxt, voff, tile);
   }
 }

@@ -404,6 +404,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->d.SW = twx::state_words(n);
   e->d.CH = twx::state_chunks(n);
   e->d.CHT = twx::total_chunks(n);
+  e->d.ts = tile_shift(e->d.CHT);
   e->jpos = 0;
   e->period = env_int("TWX_JOURNAL_PERIOD", default_period(n), 1, twx::kJournalSlots);
   e->pingpong = env_int("TWX_PINGPONG", 1, 0, 1) != 0;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   constexpr int BPW = 32;                   // boards per wave
   constexpr int RS = BPW * 4, GS = 2 * RS;  // chunk-row / word-group stride of the LDS image, in dwords
   constexpr int NJ = (CHT + 1) / 2;         // chunks a lane moves: 2j + half
-  constexpr int NG = (NJ + 3) / 4;          // per-lane offset registers (4 even chunks = 8 KiB each)
+  constexpr int NG = (NJ + 7) / 8;          // per-lane offset registers (8 chunk pairs = 8 KiB each)
   constexpr bool kOddTail = (CHT & 1) != 0; // the upper lane's last chunk does not exist
 #define plane_off(p) ((((p) >> 2) * RS) + ((p) & 3))
   constexpr int oR = plane_off(twx::kPlaneRed), oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
@@ -87,12 +87,10 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     const uint32_t k = __builtin_amdgcn_readfirstlane(tv) - tbase.b[tgroup];
     return (long)nstatic * gridDim.x + (long)k * kTicketGroups + tgroup;
   };
-  // batch i -> its 32 boards: half (t & 1) of tile t >> 1
+  // batch i -> its 32 boards = one tile of the state array (tile_shift 5: CHT rows of 512 B)
+  static_assert(tile_shift(CHT) == 5, "step_pair_kernel works on 32-board tiles");
   auto batch_of = [&](long i) -> long { return (flags & kFlagReverse) ? (nbatch - 1 - i) : i; };
-  auto tile_of = [&](long i) -> char * {
-    const long t = batch_of(i);
-    return reinterpret_cast<char *>(state) + (t >> 1) * (long)(CHT * 1024) + (t & 1) * 512;
-  };
+  auto tile_of = [&](long i) -> char * { return reinterpret_cast<char *>(state) + batch_of(i) * (long)(CHT * 512); };
 
   // the last chunk (journal slots 4..7) is read only when a slot in it may hold a record (jpos > 4)
   // or when the launch rewrites everything; otherwise its LDS row is zero-filled (slot 4 may be
@@ -103,11 +101,11 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   uint32_t voff[NG];
 #pragma unroll
   for (int g = 0; g < NG; g++) {
-    voff[g] = (uint32_t)bl * 16u + (uint32_t)h * 1024u + (uint32_t)g * 8192u + 4096u;
+    voff[g] = (uint32_t)bl * 16u + (uint32_t)h * 512u + (uint32_t)g * 8192u + 4096u;
     asm volatile("" : "+v"(voff[g]));
   }
   // the last chunk of an odd count belongs to the lower lane (the upper one's would be chunk CHT)
-  uint32_t voff_tail = (uint32_t)bl * 16u + (uint32_t)((NJ - 1) / 4) * 8192u + 4096u;
+  uint32_t voff_tail = (uint32_t)bl * 16u + (uint32_t)((NJ - 1) / 8) * 8192u + 4096u;
   asm volatile("" : "+v"(voff_tail));
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   const uint32_t lds_lane = (uint32_t)(uintptr_t)((lds_u32 *)lds) + (uint32_t)h * 512u + (uint32_t)bl * 16u;
@@ -539,7 +537,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     // ---- stream back: lane moves chunks 2j + h ----
     char *const tile_cur = tile_of(idx);
     auto chunk_ptr = [&](int c) -> uint4 * {
-      return reinterpret_cast<uint4 *>(tile_cur + ((uint32_t)bl * 16u + (uint32_t)c * 1024u));
+      return reinterpret_cast<uint4 *>(tile_cur + ((uint32_t)bl * 16u + (uint32_t)c * 512u));
     };
     const bool wr = !(kAblate & 16);
     if (compact) {

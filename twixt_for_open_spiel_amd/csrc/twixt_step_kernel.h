@@ -49,10 +49,12 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   static_assert(CHT == 2 * W + 1 + twx::kJournalChunks && W <= 32, "layout");
   // whole-batch launches on the tiled layout address a batch as one contiguous tile and keep
   // the prefetched batch in AGPRs (big boards: one wave per SIMD owns all 512 registers)
-  constexpr bool FAST = !SUB && BPW == 64 && TWX_TILED != 0;
+  constexpr int TS = tile_shift(CHT);         // boards per tile of the state array: 64, or 32 for N >= 19
+  constexpr int RB = 16 << TS;                // bytes of a chunk row of a tile
+  constexpr bool FAST = !SUB && BPW == 64;
   constexpr bool AG = FAST && CHT > TWX_SMALL_CHT;
   constexpr bool NT = CHT > TWX_PLAIN_STORE_CHT;  // non-temporal write-back where the board stream is the bound
-  constexpr int NG = (CHT + kChunksPerOffset - 1) / kChunksPerOffset;
+  constexpr int NG = (CHT * RB + 8191) / 8192;  // per-lane offset registers: one per 8 KiB of a tile
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
 
@@ -113,12 +115,15 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   };
   long round = 0;  // batches this wave has begun
   uint32_t tv = (dyn && nstatic == 1) ? draw() : 0u;
-  // FAST: byte offset of this lane's 16 bytes inside chunk 8g+4 of a tile (g = 0..NG-1), and the
-  // tile of batch idx (scalar).  lds_lane: LDS byte address of this lane's slot in chunk row 0.
+  // FAST: byte offset of this lane's 16 bytes inside its tile, + 8 KiB * g + 4 KiB (the loads'
+  // immediates reach -4 KiB .. +4 KiB), and the first tile of batch idx (scalar; a batch is one
+  // 64-board tile or two consecutive 32-board tiles: CHT KiB either way).  lds_lane: LDS byte
+  // address of this lane's slot in chunk row 0.
+  const uint32_t lane_off = (uint32_t)(lane >> TS) * (uint32_t)(CHT * RB) + (uint32_t)(lane & ((1 << TS) - 1)) * 16u;
   uint32_t voff[NG];
 #pragma unroll
   for (int g = 0; g < NG; g++) {
-    voff[g] = (uint32_t)lane * 16u + (uint32_t)g * (kChunksPerOffset * 1024u) + 4096u;
+    voff[g] = lane_off + (uint32_t)g * 8192u + 4096u;
     asm volatile("" : "+v"(voff[g]));  // stays a register: not re-derived per load
   }
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -132,14 +137,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // rolling compaction); otherwise its LDS row is zero-filled if slot 4 is about to be written
   const bool need_j2 = twx::kJournalChunks != 2 || jpos_arg > 4 || (flags & (kFlagCompact | kFlagRolling)) != 0;
   if constexpr (FAST) {
-    tile_load<0, CHT - 1, AG>(nxt, voff, tile_of(idx));
-    if (need_j2) tile_load<CHT - 1, CHT, AG>(nxt, voff, tile_of(idx));
+    tile_load<0, CHT - 1, AG, TS>(nxt, voff, tile_of(idx));
+    if (need_j2) tile_load<CHT - 1, CHT, AG, TS>(nxt, voff, tile_of(idx));
     vm_wait_all();  // first batch: nothing to overlap with
   } else {
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b0, bpad, CHT)];
+    for (int j = 0; j < NJ; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b0, TS, CHT)];
 #pragma unroll
     for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
@@ -198,14 +203,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FAST) {
       if constexpr (c1 == NJ) {
-        tile_load<c0, c1 - 1, AG>(nxt, voff, tile_next);
-        if (need_j2) tile_load<c1 - 1, c1, AG>(nxt, voff, tile_next);
+        tile_load<c0, c1 - 1, AG, TS>(nxt, voff, tile_next);
+        if (need_j2) tile_load<c1 - 1, c1, AG, TS>(nxt, voff, tile_next);
       } else {
-        tile_load<c0, c1, AG>(nxt, voff, tile_next);
+        tile_load<c0, c1, AG, TS>(nxt, voff, tile_next);
       }
     } else {
 #pragma unroll
-      for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, bpad, CHT)];
+      for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, TS, CHT)];
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -590,9 +595,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   char *const tile_cur = tile_of(idx);
   auto chunk_ptr = [&](int c) -> uint4 * {  // where chunk c of this lane's board lives
     if constexpr (FAST)
-      return reinterpret_cast<uint4 *>(tile_cur + ((uint32_t)lane * 16u + (uint32_t)c * 1024u));
+      return reinterpret_cast<uint4 *>(tile_cur + (lane_off + (uint32_t)c * (uint32_t)RB));
     else
-      return state + chunk_index(c, board, bpad, CHT);
+      return state + chunk_index(c, board, TS, CHT);
   };
   if (compact) {
 #pragma unroll

@@ -10,6 +10,7 @@
 // ---------------------------------------------------------------------------
 struct Dims {
   int n, W, SW, CH, CHT;  // CH: state chunks (planes + scalars); CHT: + journal chunks
+  int ts;                 // tile_shift(CHT): boards per tile of the state array = 1 << ts
   long batch, bpad;
 };
 
@@ -19,10 +20,10 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v, int j) {
 
 // word i of plane p / scalar j of board b in the interleaved internal layout
 __device__ __forceinline__ uint32_t plane_word(const uint4 *state, const Dims &d, long b, int p, int i) {
-  return comp(state[chunk_index((2 * i + (p >> 2)), b, d.bpad, d.CHT)], p & 3);
+  return comp(state[chunk_index((2 * i + (p >> 2)), b, d.ts, d.CHT)], p & 3);
 }
 __device__ __forceinline__ uint32_t scalar_word(const uint4 *state, const Dims &d, long b, int j) {
-  return comp(state[chunk_index((2 * d.W), b, d.bpad, d.CHT)], j);
+  return comp(state[chunk_index((2 * d.W), b, d.ts, d.CHT)], j);
 }
 
 __global__ void reset_kernel(uint4 *state, Dims d, const uint32_t *init, const int32_t *ids, long n) {
@@ -37,7 +38,7 @@ __global__ void reset_kernel(uint4 *state, Dims d, const uint32_t *init, const i
   }
   uint4 v;  // init is in internal chunk order; scalars and journal chunks are zero
   v.x = init[4 * c + 0]; v.y = init[4 * c + 1]; v.z = init[4 * c + 2]; v.w = init[4 * c + 3];
-  state[chunk_index(c, b, d.bpad, d.CHT)] = v;
+  state[chunk_index(c, b, d.ts, d.CHT)] = v;
 }
 
 // canonical (include/twixt_hip.h) order out: one thread per (board, word)
@@ -70,7 +71,7 @@ __global__ void import_kernel(uint4 *state, Dims d, const int32_t *ids, long n, 
     const uint32_t *sc = src + twx::kNumPlanes * d.W;
     v.x = sc[0]; v.y = sc[1]; v.z = sc[2]; v.w = sc[3];
   }
-  state[chunk_index(c, b, d.bpad, d.CHT)] = v;
+  state[chunk_index(c, b, d.ts, d.CHT)] = v;
 }
 
 __global__ void copy_kernel(uint4 *dst, Dims dd, const int32_t *dst_ids, const uint4 *src, Dims sd,
@@ -81,7 +82,7 @@ __global__ void copy_kernel(uint4 *dst, Dims dd, const int32_t *dst_ids, const u
   if (c >= dd.CH) return;
   const long db = dst_ids[j], sb = src_ids[j];
   if (db < 0 || db >= dd.batch || sb < 0 || sb >= sd.batch) return;
-  dst[chunk_index(c, db, dd.bpad, dd.CHT)] = src[chunk_index(c, sb, sd.bpad, sd.CHT)];
+  dst[chunk_index(c, db, dd.ts, dd.CHT)] = src[chunk_index(c, sb, sd.ts, sd.CHT)];
 }
 
 // tw.h:86-90 as a mask: one thread per (board, mask word)
@@ -115,11 +116,11 @@ __global__ void status_kernel(const uint4 *state, Dims d, const int32_t *ids, lo
   if (j >= n) return;
   const long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) return;
-  const uint4 s = state[chunk_index((d.CH - 1), b, d.bpad, d.CHT)];
+  const uint4 s = state[chunk_index((d.CH - 1), b, d.ts, d.CHT)];
   uint32_t counter = s.x & 0xffffu, res = s.y & 0xffu, move_one = s.x >> 16, swapped = (s.y >> 8) & 1u;
   // the stored scalars are as old as the planes: advance them by the journal (empty slots are zero)
   for (int k = 0; k < twx::kJournalChunks; k++) {
-    const uint4 jr = state[chunk_index(d.CH + k, b, d.bpad, d.CHT)];
+    const uint4 jr = state[chunk_index(d.CH + k, b, d.ts, d.CHT)];
     twx::journal_scalars(jr.x, counter, move_one, res, swapped);
     twx::journal_scalars(jr.y, counter, move_one, res, swapped);
     twx::journal_scalars(jr.z, counter, move_one, res, swapped);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
   const long j = blockIdx.x;  // output row
   long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) b = 0;  // host validated; keep the block's barriers uniform
-  for (int c = lane; c < 2 * W + 1; c += kWave) sst[c] = state[chunk_index(c, b, d.bpad, d.CHT)];
+  for (int c = lane; c < 2 * W + 1; c += kWave) sst[c] = state[chunk_index(c, b, d.ts, d.CHT)];
   for (int i = lane; i < npos; i += kWave) { feat[0][i] = 0; feat[1][i] = 0; }
   __syncthreads();
   const uint32_t *w = reinterpret_cast<const uint32_t *>(sst);
