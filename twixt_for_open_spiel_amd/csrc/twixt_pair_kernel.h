@@ -26,15 +26,6 @@
 // Reference lines: Board::ApplyAction tb.cc:457-499, SetPegAndLinks tb.cc:501-571, UpdateResult
 // tb.cc:192-207, LegalActions / DoApplyAction tw.h:86-104, Board::Board tb.cc:168-276.
 
-#ifndef TWX_FLOOD_REP
-#define TWX_FLOOD_REP 2
-#endif
-#ifndef TWX_STORE_EARLY
-#define TWX_STORE_EARLY 0
-#endif
-#ifndef TWX_DIRTY_LINES
-#define TWX_DIRTY_LINES 0
-#endif
 // both lanes of a pair get the value of the lower (x) and of the upper (y) lane
 struct PairVal { uint32_t lo, hi; };
 __device__ __forceinline__ PairVal pair_swap(uint32_t v) {
@@ -162,6 +153,14 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     load_slice(I0{}, IP1{}, tile_next);
     __builtin_amdgcn_sched_barrier(0);
 
+    if constexpr ((kAblate & 2048) != 0) {  // diagnostic 2048: nothing but the board stream
+      load_slice(IP1{}, IP2{}, tile_next);
+      load_slice(IP2{}, INJ{}, tile_next);
+      vm_wait_all();
+      const long idx_after0 = (long)blockIdx.x + (round + 2) * gridDim.x;
+      idx = idx_next; idx_next = idx_after0; round++;
+      continue;
+    }
     const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
     uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
     uint32_t result = sv.y & 0xffu, swapped = (sv.y >> 8) & 1u;
@@ -175,7 +174,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     }
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++)
-      if (s < jpos && !(kAblate & 4)) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
+      if (s < jpos) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
     const bool was_reset = random && (flags & kFlagAutoReset) && result != 0u && inb;
     if (__ballot(was_reset)) {  // rare: one board in ~520 per step
       if (was_reset) {
@@ -493,7 +492,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         for (;;) {
           uint32_t fresh = 0u;
 #pragma unroll
-          for (int rep = 0; rep < TWX_FLOOD_REP; rep++) {  // expansions per exit test
+          for (int rep = 0; rep < 2; rep++) {  // two expansions per exit test (1..4 measured alike)
             // forward: a frontier cell with link e reaches (c+dx, y+dy); backward: cell (c,y) whose
             // link e ends in the frontier.  Columns move by DPP wave shifts, rows by bit shifts.
             const uint32_t a1 = ((front & lk[0]) << 2) | ((front & lk[3]) >> 2);
@@ -529,9 +528,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
 
     // The prefetched batch has had the whole step to arrive: retire its loads here, before this
     // batch's stores are issued (loads and stores share one in-order counter).
-#if !TWX_STORE_EARLY
     vm_wait_all();
-#endif
     const long idx_after = drawn ? ticket_batch(tv) : (long)blockIdx.x + (round + 2) * gridDim.x;
 
     // ---- stream back: lane moves chunks 2j + h ----
@@ -551,28 +548,6 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       }
       // flag chunks a flood fill changed
       uint32_t dd = (was_reset || !wr || (kAblate & 2)) ? 0u : dirty;
-#if TWX_DIRTY_LINES
-      // ... written as whole 128-byte lines: the 8 boards that share a line all store their copy
-      // of the chunk (any LDS chunk may be written back at any time: a later replay of the journal
-      // re-applies the same bits), so HBM never sees a 16-byte partial write.  One dirty board per
-      // trip, its chunks two at a time (lower lanes the lowest dirty group, upper lanes the next).
-      uint64_t dtodo = __ballot(dd != 0u) & 0xffffffffull;
-      while (dtodo) {
-        const int s = (int)__ffsll((unsigned long long)dtodo) - 1;
-        dtodo &= dtodo - 1;
-        uint32_t ds = (uint32_t)__builtin_amdgcn_readlane((int)dd, s);
-        const bool grp = (bl >> 3) == (s >> 3);
-        while (ds) {
-          const uint32_t d1 = ds & (ds - 1u);
-          const uint32_t mine = up ? d1 : ds;
-          if (mine && grp) {
-            const int c = 2 * (__ffs((int)mine) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
-            tile_store<true>(chunk_ptr(c), lds4[c * BPW + bl]);
-          }
-          ds = d1 & (d1 - 1u);
-        }
-      }
-#else
       // ... every dirty board walks its own mask, two chunks per trip (lower lane the lowest dirty
       // group, upper lane the next one)
       while (__ballot(dd != 0u)) {
@@ -585,16 +560,12 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         }
         dd = d1 & (d1 - 1u);
       }
-#endif
       if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
         for (int j = 0; j < NJ; j++)
           if (was_reset && wr && 2 * j + h < CHT) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
       }
     }
-#if TWX_STORE_EARLY  // experiment: the wait for the prefetch also covers the stores just issued
-    vm_wait_all();
-#endif
     if (inb && !flush && !up) {
       if (status) {
         uint8_t st = (uint8_t)(result | (swapped << 5));

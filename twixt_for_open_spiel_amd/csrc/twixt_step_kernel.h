@@ -16,8 +16,9 @@
 // words write those chunks.
 // Diagnostic builds only (-DTWX_ABLATE=mask, tools/README.md): leave a phase out to measure what
 // it really costs inside the overlapped loop (results are then wrong by construction).
-//   1 flood fill   2 dirty-chunk stores   4 journal replay   8 apply   16 every store   32 LDS fill
-//   64 (pair kernel) dirty-chunk loop runs but stores nothing
+//   1 flood fill   2 dirty-chunk stores   4 journal replay (the planes' part; the scalars still advance)
+//   8 apply   16 every store   32 LDS fill   64 (pair kernel) dirty-chunk loop runs but stores nothing
+//   2048 (pair kernel) nothing but the board stream: loads and the wait for them
 #ifndef TWX_ABLATE
 #define TWX_ABLATE 0
 #endif
@@ -246,7 +247,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
 #pragma unroll
   for (int s = 0; s < twx::kJournalSlots - 1; s++)
-    if (s < jpos && !(kAblate & 4)) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
+    if (s < jpos) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
 
   if (random && (flags & kFlagAutoReset) && result != 0u && inb) {
     // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in place ----
