@@ -15,8 +15,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte v
 // i.e. the 8 planes are interleaved word by word: everything about the 32 cells
 // 32i..32i+31 sits in two adjacent chunks.  One address computation per cell /
 // column then reaches every plane through immediate offsets.
-// HBM: state[chunk][board] (uint4); LDS image of a wave: [chunk][lane] (uint4),
-// so chunk c of lane l starts at dword c*256 + l*4.
+// HBM: tiles of 32 or 64 boards, state[tile][chunk][board of the tile] (uint4, chunk_index()
+// below); LDS image of a wave: [chunk][board slot] (uint4).
 // ---------------------------------------------------------------------------
 
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {

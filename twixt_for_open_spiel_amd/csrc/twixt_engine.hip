@@ -3,19 +3,21 @@
 //
 // Hot path (reference: twixtboard.cc:457-588 Board::ApplyAction /
 // SetPegAndLinks / ExploreLocalGraph / UpdateResult, twixt.h:86-104
-// LegalActions / DoApplyAction) = step_kernel<N>:
-//   * one wavefront = 64 boards, one board per lane;
-//   * the wave streams its 64 boards (CH 16-byte chunks each, layout
-//     state[chunk][board]) into LDS with coalesced 1 KiB loads, works on them
-//     there (data-dependent word access is a single ds_read), and streams them
-//     back with 1 KiB stores -> HBM traffic is exactly 2 x state bytes / step;
-//   * legal mask + k-th-legal-action pick are whole-plane popcount scans;
-//   * the 8-direction link scan and the 72 crossing probes are constant-mask
-//     tests on a 5x7 window of the link planes (twixt_geom.h kCross);
-//   * the rare border-flag flood fill (5.8 % of steps, twixtboard.cc:573-588)
-//     is done by the whole wave cooperating on one board at a time
-//     (lane = board column, frontier expansion with shuffles + ballot), so a
-//     long fill never leaves 63 lanes idle behind one.
+// LegalActions / DoApplyAction): one fused kernel launch = one env step on
+// every board of a handle.
+//   * step_pair_kernel<N> (twixt_pair_kernel.h, N >= 19): 32 boards per wave,
+//     two lanes per board, 8 waves per CU;
+//   * step_kernel64[_small]<N,SUB> (twixt_step_kernel.h): 64 boards per wave,
+//     one lane per board: N <= 18, listed-boards and fused play-out launches.
+//   Both: a persistent wave streams its boards (CHT 16-byte chunks each, tiles
+//   of the state array, twixt_device_common.h) into LDS with coalesced 1 KiB
+//   loads prefetched a batch ahead, works on them there, and writes back one
+//   journal chunk per board -- the state is log-structured;
+//   legal mask + k-th-legal-action pick are whole-plane popcount scans; the
+//   8-direction link scan and the 72 crossing probes are constant-mask tests on
+//   a 5x7 window of the link planes (twixt_geom.h kCross); the border-flag
+//   flood fill (twixtboard.cc:573-588) is done by the wave cooperating on two
+//   boards at a time (lane = board column, DPP shifts + ballot).
 // Integer / bitwise work only: no MFMA, the bound is HBM bandwidth.
 #include <hip/hip_runtime.h>
 
@@ -69,7 +71,7 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
   const long nbatch = ids ? (nsub + bpw - 1) / bpw : bpad / bpw;
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
   const size_t rows = (bpw == 64) ? twx::Geo<N>::CHT : 2 * ((twx::Geo<N>::CHT + 1) / 2);
-  const size_t lds_bytes = rows * bpw * 16;  // 39 KiB (64 boards) or 20 KiB (32 boards) at N=24
+  const size_t lds_bytes = rows * bpw * 16;  // 39 KiB at N=24
 #define TWX_LAUNCH(K)                                                                                      \
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
                      actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, ticket, ticket_base, nstatic)

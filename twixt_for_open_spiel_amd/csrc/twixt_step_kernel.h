@@ -8,12 +8,12 @@
 //
 // Log-structured state: between two compactions a launch does not
 // rewrite the planes; it appends one 32-bit record of the move to the board's
-// journal (slot `jpos`, the same for every board) and writes back only the
-// scalars chunk and that journal chunk.  The next launches replay slots
-// 0..jpos-1 on top of the planes they stream in.  Every `period`-th launch
-// (kFlagCompact) writes everything and clears the journal.  Lanes that
-// auto-reset write their whole board; lanes whose flood fill changed flag
-// words write those chunks.
+// journal (slot `jpos`, the same for every board) and writes back only that
+// journal chunk: the record carries the scalars and the single-cell fills
+// (twixt_geom.h).  The next launches replay slots 0..jpos-1 on top of the planes
+// they stream in.  Every `period`-th launch (kFlagCompact) writes everything and
+// clears the journal.  Lanes that auto-reset write their whole board; lanes whose
+// multi-cell flood fill changed flag words write those chunks.
 // Diagnostic builds only (-DTWX_ABLATE=mask, tools/README.md): leave a phase out to measure what
 // it really costs inside the overlapped loop (results are then wrong by construction).
 //   1 flood fill   2 dirty-chunk stores   4 journal replay (the planes' part; the scalars still advance)
@@ -649,7 +649,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
 }
 #undef plane_off
 
-// 64 boards per wave: 39 KiB LDS image, 4 waves per CU, all 512 registers of the SIMD
+// 64 boards per wave, big boards (N >= 19: listed-boards / play-out launches, and whole-batch steps
+// under TWX_PAIR=0): 39 KiB LDS image at N=24, 4 waves per CU, all 512 registers of the SIMD
 template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel64(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
