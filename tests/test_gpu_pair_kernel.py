@@ -21,12 +21,6 @@ def torch_mod():
     return torch
 
 
-def oracle_status_trace(ob, n, seed, first, batch, steps):
-    """result / move_counter / current_player after every step, by replaying the oracle."""
-    ref = ob.rollout_batch(n, seed, first, batch, steps, True, want_cells=True, want_trace=True)
-    return ref
-
-
 @pytest.mark.parametrize("n,batch,steps", [(19, 1000, 420), (21, 700, 150), (24, 1500, 640)])
 @pytest.mark.parametrize("pair", [1, 0])
 def test_every_step_against_the_oracle(torch_mod, n, batch, steps, pair, monkeypatch):
@@ -107,6 +101,28 @@ def test_pair_kernel_batch_order(torch_mod, dynamic, nstatic, monkeypatch):
     assert np.array_equal(stat.cpu().numpy(), ref["status"][:, -1])
     compare_planes(env, ref["planes"], what="dynamic=%d nstatic=%d" % (dynamic, nstatic))
     env.close()
+
+
+@pytest.mark.parametrize("batch", [1, 31, 33, 64, 65, 97])
+@pytest.mark.parametrize("pair", [1, 0])
+def test_ragged_batches(torch_mod, batch, pair, monkeypatch):
+    """Batches that do not fill a wave or a tile (the allocation is padded to 64 boards; padding
+    boards never move and are never reported): a few boards, whole-batch steps, N=24 and N=19."""
+    import oracle_binding as ob
+    monkeypatch.setenv("TWX_PAIR", str(pair))
+    for n, steps in ((24, 60), (19, 40)):
+        env = make_env(n, batch, first=7)
+        acts = []
+        for _ in range(steps):
+            a, st = env.step_random(3, True)
+            acts.append(a.cpu().numpy())
+        ref = ob.rollout_batch(n, 3, 7, batch, steps, True, want_trace=True)
+        assert np.array_equal(np.stack(acts, axis=1), ref["actions"])
+        assert np.array_equal(st.cpu().numpy(), ref["status"][:, -1])
+        compare_planes(env, ref["planes"], what="batch %d N=%d" % (batch, n))
+        res, mc, cp = env.status()
+        assert mc.shape[0] == batch and int(mc.min()) == steps
+        env.close()
 
 
 def test_kernels_alternate_on_one_state(torch_mod, monkeypatch):
