@@ -7,6 +7,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import twixt_for_open_spiel_amd._lib as L
+if len(sys.argv) > 2:  # usage: obs_bench.py [boards] [lib.so]
+    L.LIB_PATH = os.path.abspath(sys.argv[2])
 from twixt_for_open_spiel_amd import TwixtBatchEnv
 
 n, B = 24, int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18

@@ -185,6 +185,9 @@ __global__ void cells_kernel(const uint4 *state, Dims d, const int32_t *ids, lon
 //      blocked east} (tw.cc:83-98) stored at its tensor position (tb.cc:590-597: red
 //      (N-1-y, x-1), blue (N-1-x, N-2-y)) in a red and a blue feature plane in LDS;
 //   3. the wave streams the 12 planes out as coalesced 16-byte stores.
+#ifndef TWX_OBS_NT
+#define TWX_OBS_NT 1
+#endif
 constexpr int kObsMaxPos = TWX_MAX_BOARD_SIZE * (TWX_MAX_BOARD_SIZE - 2);
 __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restrict__ state, Dims d,
                                                             const int32_t *__restrict__ ids,
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
     feat[colour][pos] = (uint8_t)f;
   }
   __syncthreads();
-  float4 *o = reinterpret_cast<float4 *>(out + j * (long)(12 * npos));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 *o = reinterpret_cast<f32x4 *>(out + j * (long)(12 * npos));
   const uint32_t magic = (1u << 24) / (uint32_t)npos + 1u;  // e / npos == (e * magic) >> 24 for e < 12*npos <= 6336
   for (int j = lane; j < 3 * npos; j += kWave) {  // 12*npos floats = 3*npos float4
     float v[4];
@@ -233,7 +237,12 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
       const int colour = k >= 6 ? 1 : 0;
       v[q] = ((feat[colour][pos] >> (k - 6 * colour)) & 1u) ? 1.0f : 0.0f;
     }
-    o[j] = make_float4(v[0], v[1], v[2], v[3]);
+    const f32x4 vv = {v[0], v[1], v[2], v[3]};
+#if TWX_OBS_NT
+    __builtin_nontemporal_store(vv, o + j);  // write-only output, 25 KB per board: keep it out of the caches
+#else
+    o[j] = vv;
+#endif
   }
 }
 
