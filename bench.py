@@ -192,6 +192,29 @@ def observation_rate(env, nboards, reps=10):
             "kernel": "observation_kernel", "bound": "hbm (writes)"}
 
 
+def small_batch_latency(device, seed, cases=((12, 2048), (24, 16384)), steps=300):
+    """Secondary: what a search sees (BASELINE config 5's leaf batches): a few thousand boards are
+    one round of a few dozen waves, so a step costs the latency of one wave's step, not bandwidth."""
+    import torch
+    from twixt_for_open_spiel_amd import TwixtBatchEnv
+    out = []
+    for n, b in cases:
+        env = TwixtBatchEnv(n, b, device)
+        for _ in range(60):
+            env.step_random(seed, True, want_actions=False, want_status=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            env.step_random(seed, True, want_actions=False, want_status=False)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        out.append({"board_size": n, "batch": b, "us_per_step": us, "env_steps_per_s": b / (us * 1e-6)})
+        env.close()
+    return out
+
+
 def shard_first_board(rank, batch_per_gpu):
     """Rank r owns the contiguous global board ids [r*B, (r+1)*B)."""
     return rank * batch_per_gpu
@@ -430,6 +453,7 @@ def main(argv=None):
             out["observation"] = observation_rate(env, min(B, 1 << 17))
         if env is not None and world == 1 and not args.no_rollout:
             out["fused_rollout"] = fused_rollout(env, args.seed)
+            out["small_batch"] = small_batch_latency(dev, args.seed)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(n, args.seed)
         print(json.dumps(out), flush=True)
