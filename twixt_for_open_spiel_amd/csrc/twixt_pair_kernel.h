@@ -11,7 +11,8 @@
 // holds 32 boards (20 KiB image, eight waves per CU, two per SIMD) and the two lanes l and l+32
 // SHARE board l:
 //   * memory: lane l moves the even chunks of its board, lane l+32 the odd ones (loads, LDS fill,
-//     stores): the same bytes per board as before, each instruction still 2 x 512 B contiguous;
+//     stores); the state array is tiled by 32 boards for these sizes, so every instruction still
+//     covers one contiguous KiB;
 //   * legal mask / k-th legal action: each lane scans half of the word groups; counts and the
 //     chosen cell are combined with one v_permlane32_swap each;
 //   * link scan (tb.cc:501-555): the lower lane reads link planes NNE/ENE and the knight
@@ -63,7 +64,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   const bool compact = (flags & kFlagCompact) != 0;
   const bool flush = (flags & kFlagFlush) != 0;
   const bool random = (flags & kFlagRandom) != 0;
-  const long nbatch = bpad / BPW;  // batches of 32 boards: the two halves of every 64-board tile
+  const long nbatch = bpad / BPW;  // batches of 32 boards = tiles of the state array
 
   // ---- batch order: as step_kernel64 (static rounds, then tickets) ----
   const bool dyn = (flags & kFlagDynamic) != 0;
