@@ -42,7 +42,7 @@ for _ in range(R):
     compact = [x + y for x, y in zip(compact, run(1))]
 for title, acc, launches in (("journal launches", normal, 7 * R), ("compaction launches", compact, R)):
     tot = sum(acc)
-    wavesteps = launches * (B // 64)
+    wavesteps = launches * (B // (32 if os.environ.get('TWX_PAIR', '1') != '0' else 64))
     print("--- %s ---" % title)
     for i, nm in enumerate(names):
         print("%-32s %9.1f cycles/wave-step  %5.1f %%" % (nm, acc[i] / wavesteps, 100.0 * acc[i] / tot))

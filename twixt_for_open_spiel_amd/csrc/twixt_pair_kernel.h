@@ -121,6 +121,15 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   load_slice(I0{}, INJ{}, tile_of(idx));
   vm_wait_all();  // first batch: nothing to overlap with
   long idx_next = (dyn && nstatic == 1) ? ticket_batch(tv) : idx + gridDim.x;
+  // NOTHING the compiler tracks in its vmcnt bookkeeping (a load, an atomic with a result) may be
+  // consumed between the issue of the prefetch and vm_wait_all(): the compiler does not see the
+  // prefetch loads, so its own `s_waitcnt vmcnt(0)` for such a result would wait for the whole
+  // prefetch in the middle of the step (it did, for the ticket and for the external action, until
+  // round 2: the step then ran at the memory LATENCY, not its bandwidth).  So the ticket of a
+  // batch is drawn right after the wait of the batch before and read after the next wait, and
+  // the external action is loaded and waited for before the prefetch is issued.
+  bool drawn = dyn && round + 2 >= nstatic;  // is the batch after next a ticket?
+  if (drawn) tv = draw();
 
   // loop-invariant per-lane constants of the split
   const uint32_t hm = up ? 0xffffffffu : 0u;
@@ -140,12 +149,16 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   uint32_t *const sc = me + CS * RS;      // scalars
   uint32_t *const jn = me + CJ * RS;      // journal slot s at jn[(s >> 2) * RS + (s & 3)]
 
+  STAMP_DECL;  // (diagnostic -DTWX_STAMPS build only: cycles per phase, tools/stamps.py)
   while (idx < nbatch) {
-    const bool drawn = dyn && round + 2 >= nstatic;  // is the batch after next a ticket?
-    if (drawn) tv = draw();
+    STAMP(0);  // loop end / store issue of the previous batch
     const long row = batch_of(idx) * BPW + bl;  // = board: whole-batch launches only
     const bool inb = row < batch;
-    const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
+    int a_ext = -1;
+    if (!random && !flush) {  // wave-uniform: external actions (twx_step)
+      if (inb) a_ext = actions[row];
+      asm volatile("" : "+v"(a_ext));  // the compiler's wait for this load belongs HERE, before the prefetch
+    }
     pair_tile_fill<0, NJ>(lds_lane, nxt);
     if (!need_j2 && !up) *reinterpret_cast<uint4 *>(lds + (bl << 2) + (CHT - 1) * RS) = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
@@ -153,6 +166,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     __builtin_amdgcn_sched_barrier(0);
     load_slice(I0{}, IP1{}, tile_next);
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);  // LDS fill + first prefetch slice
 
     if constexpr ((kAblate & 2048) != 0) {  // diagnostic 2048: nothing but the board stream
       load_slice(IP1{}, IP2{}, tile_next);
@@ -237,6 +251,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       }
     }
     wave_sync();
+    STAMP(2);  // scalars, reset, journal replay
     __builtin_amdgcn_sched_barrier(0);
     load_slice(IP1{}, IP2{}, tile_next);
     __builtin_amdgcn_sched_barrier(0);
@@ -309,6 +324,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       illegal = inb && !(open && legal);  // tw.h:95-97 (terminal: LegalActions() is empty)
       act = act && legal;
     }
+    STAMP(3);  // legal mask + select
     __builtin_amdgcn_sched_barrier(0);
     load_slice(IP2{}, INJ{}, tile_next);
     __builtin_amdgcn_sched_barrier(0);
@@ -441,6 +457,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
                 (result << twx::kJResultShift) | fill1;
       }
     }
+    STAMP(5);  // apply
     // scalars (s3 = the board's dirty mask during the flood below) and this move's record
     // (a board that was reset in a journalling launch is written whole with the scalars of the
     // EMPTY board: its first move is in the record, and stored scalars + records = the truth)
@@ -527,10 +544,15 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     sc[3] = 0u;
     wave_sync();
 
+    STAMP(6);  // flood fill
     // The prefetched batch has had the whole step to arrive: retire its loads here, before this
     // batch's stores are issued (loads and stores share one in-order counter).
     vm_wait_all();
+    STAMP(7);  // wait for the prefetched batch
     const long idx_after = drawn ? ticket_batch(tv) : (long)blockIdx.x + (round + 2) * gridDim.x;
+    // the ticket of the batch after the next one, if the next batch exists (the host counts on it)
+    drawn = dyn && round + 3 >= nstatic && idx_next < nbatch;
+    if (drawn) tv = draw();
 
     // ---- stream back: lane moves chunks 2j + h ----
     char *const tile_cur = tile_of(idx);
@@ -547,7 +569,9 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         const int c = CJ + (jpos >> 2);
         if (wr && !up) tile_store<true>(chunk_ptr(c), lds4[c * BPW + bl]);
       }
-      // flag chunks a flood fill changed
+      STAMP(9);  // ticket + journal chunk store
+      // flag chunks a flood fill changed (taking the first one along in the journal store's idle
+      // upper lanes measured 1.9 % SLOWER: scattered lanes make that instruction expensive)
       uint32_t dd = (was_reset || !wr || (kAblate & 2)) ? 0u : dirty;
       // ... every dirty board walks its own mask, two chunks per trip (lower lane the lowest dirty
       // group, upper lane the next one)
@@ -561,12 +585,14 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         }
         dd = d1 & (d1 - 1u);
       }
+      STAMP(10);  // dirty flag chunks
       if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
         for (int j = 0; j < NJ; j++)
           if (was_reset && wr && 2 * j + h < CHT) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
       }
     }
+    STAMP(11);  // reset boards / compaction
     if (inb && !flush && !up) {
       if (status) {
         uint8_t st = (uint8_t)(result | (swapped << 5));
@@ -578,10 +604,12 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       if (actions_out) actions_out[row] = a;
     }
     wave_sync();
+    STAMP(8);  // stream back + status
     idx = idx_next;
     idx_next = idx_after;
     round++;
   }  // batch loop
+  STAMP_FLUSH;
 }
 #undef plane_off
 

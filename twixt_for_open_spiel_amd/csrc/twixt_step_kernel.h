@@ -150,9 +150,13 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
   long idx_next = (dyn && nstatic == 1) ? ticket_batch(tv) : idx + gridDim.x;
-  while (idx < nbatch) {
-  const bool drawn = dyn && round + 2 >= nstatic;  // is the batch after next a ticket?
+  // Nothing the compiler tracks in its vmcnt bookkeeping may be consumed between the issue of the
+  // (asm, untracked) prefetch and the wait for it: see step_pair_body.  The ticket of a batch is
+  // drawn right after the wait of the batch before and read after the next wait; the external
+  // action is loaded and waited for before the prefetch is issued.
+  bool drawn = dyn && round + 2 >= nstatic;  // is the batch after next a ticket?
   if (drawn) tv = draw();
+  while (idx < nbatch) {
   STAMP(0);  // loop overhead / previous stores issue
   // Rolling compaction (TWX_ROLLING=1, off by default): batch b is at journal position
   // (phase + b) mod period, so every launch compacts one batch in `period` instead of every
@@ -175,7 +179,11 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   const bool inb = (unsigned long)board_raw < (unsigned long)batch;
   const long board = (ids && !inb) ? 0L : board_raw;  // padding lanes of a subset load board 0
   const bool wr = (!ids || inb) && !(kAblate & 16);  // subset mode: padding lanes must not store
-  const int a_ext = (!random && !flush && inb) ? actions[row] : -1;
+  int a_ext = -1;
+  if (!random && !flush) {  // wave-uniform: external actions (twx_step, twx_step_boards)
+    if (inb) a_ext = actions[row];
+    asm volatile("" : "+v"(a_ext));  // the compiler's wait for this load belongs HERE, before the prefetch
+  }
   if constexpr ((kAblate & 32) != 0) {
   } else if constexpr (FAST) {
     tile_fill<0, CHT - 1, AG>(lds_lane, nxt);
@@ -589,6 +597,9 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
   // (the draw is older than the prefetch, so it has returned as well)
   const long idx_after = drawn ? ticket_batch(tv) : (long)blockIdx.x + (round + 2) * gridDim.x;
+  // the ticket of the batch after the next one, if the next batch exists (the host counts on it)
+  drawn = dyn && round + 3 >= nstatic && idx_next < nbatch;
+  if (drawn) tv = draw();
 
   STAMP(7);  // wait for the prefetched batch
   // ---- stream back ----
