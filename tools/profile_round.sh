@@ -16,6 +16,9 @@ python3 tools/pmc_traffic.py $out/fetch $out/write $out/$tag
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $out/sqa -- $B --steps 64 --warmup 0 > $out/sqa.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/sqb -- $B --steps 64 --warmup 0 > $out/sqb.log 2>&1
 python3 tools/pmc_counters.py $out/${tag}_sq_counters.json $out/sqa $out/sqb > /dev/null
+# the bench line of the same binary, with the traffic just measured (bench.py only believes a
+# traffic file that carries this build's hash)
+cp $out/${tag}_traffic.json profiles/traffic_step_kernel_n24.json
 python3 bench.py --steps 500 --warmup 20 > $out/${tag}_bench.json 2> $out/bench.err
 rm -rf $out/stats $out/fetch $out/write $out/sqa $out/sqb
 ls -la $out
