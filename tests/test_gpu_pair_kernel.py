@@ -84,6 +84,29 @@ def test_pair_kernel_journal_periods(torch_mod, period, pingpong, monkeypatch):
     env.close()
 
 
+@pytest.mark.parametrize("period", [3, 8])
+def test_rolling_compaction_on_a_big_board(torch_mod, period, monkeypatch):
+    """TWX_ROLLING=1 (a tested option of the one-lane kernel) keeps working on the 32-board tiles
+    of N >= 19: whole-batch steps then run step_kernel64, not the pair kernel."""
+    import oracle_binding as ob
+    monkeypatch.setenv("TWX_ROLLING", "1")
+    monkeypatch.setenv("TWX_JOURNAL_PERIOD", str(period))
+    n, batch, seed = 22, 5000, 8
+    env = make_env(n, batch, first=3)
+    done = 0
+    for upto in (1, 4, 9, 30, 77, 200, 470):
+        for _ in range(upto - done):
+            env.step_random(seed, True, want_actions=False, want_status=False)
+        done = upto
+        res, mc, _ = env.status()                      # mid-period: scalars from the journal
+        ref = ob.rollout_batch(n, seed, 3, batch, upto, True)
+        sw = ref["planes"].shape[1]
+        assert np.array_equal(res.cpu().numpy(), ref["planes"][:, sw - 3] & 0xff)
+        assert np.array_equal(mc.cpu().numpy(), ref["planes"][:, sw - 4] & 0xffff)
+        compare_planes(env, ref["planes"], what="rolling period %d after %d steps" % (period, upto))
+    env.close()
+
+
 @pytest.mark.parametrize("dynamic,nstatic", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 1000)])
 def test_pair_kernel_batch_order(torch_mod, dynamic, nstatic, monkeypatch):
     """Ticket-drawn rounds on the pair kernel: one wave per CU over ~50k boards gives static
