@@ -98,6 +98,19 @@ __host__ __device__ __forceinline__ long chunk_index(long c, long b, int ts, int
   return (((b >> ts) * cht + c) << ts) + (b & ((1L << ts) - 1));
 }
 
+// The journal of a tile lives in its last kJournalChunks chunk rows as kJournalSlots rows of
+// (1 << ts) dwords, [slot][board]: record s of board b is ONE dword, and the records a launch
+// appends for the boards of a tile are one contiguous 128- or 256-byte line (round 2: a step used
+// to write a 16-byte journal chunk per board).  Dword index into the state array:
+__host__ __device__ __forceinline__ long journal_word_index(int s, long b, int ts, int cht) {
+  return ((((b >> ts) * cht + (cht - twx::kJournalChunks)) << ts) << 2) + ((long)s << ts) + (b & ((1L << ts) - 1));
+}
+template <bool NT>
+__device__ __forceinline__ void tile_store_word(uint32_t *p, uint32_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // ---------------------------------------------------------------------------
 // Tile I/O of the whole-batch step kernel (64 boards per wave): the 64 boards of a batch are ONE
 // contiguous block of CHT KiB (one 64-board tile, or two 32-board tiles), chunk c of a tile at byte

@@ -242,6 +242,19 @@ struct DeviceGuard {
   DeviceGuard device_guard_((e)->device); \
   HIP_TRY(device_guard_.err)
 
+// launch arguments change from call to call on an ordinary handle (journal position, batch
+// order, ticket bases): a captured graph would replay stale ones and silently skip or repeat
+// boards, or read stale journal slots
+int refuse_capture(const twx_env *e, hipStream_t s) {
+  if (e->period > 1 || e->pingpong || e->dynamic) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(TWX_E_ARG, "step and status functions cannot be captured into a hipGraph on this handle: create "
+                             "it with TWX_GRAPH_SAFE=1");
+  }
+  return TWX_OK;
+}
+
 // one env step (or a flush) on every board, or on the `nsub` boards listed in `ids`;
 // maintains the journal position
 int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *status, uint32_t seed,
@@ -249,14 +262,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   TWX_USE(e);
   const bool flush = (flags & kFlagFlush) != 0;
   const bool whole_step = !ids && rsteps == 1 && !flush;
-  if (e->period > 1 || e->pingpong || e->dynamic) {
-    // launch arguments change from call to call (journal position, batch order, ticket
-    // bases): a captured graph would replay stale ones and silently skip or repeat boards
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-      return fail(TWX_E_ARG, "step functions cannot be captured into a hipGraph on this handle: create it with "
-                             "TWX_GRAPH_SAFE=1");
-  }
+  if (int rc = refuse_capture(e, s)) return rc;
   if (!whole_step && !flush && e->journal_live) {
     // journals belong to the whole-batch step launches: subset and roll-out launches work
     // on materialised planes and rewrite their boards directly
@@ -573,10 +579,11 @@ int twx_status_boards(const twx_env *e, const int32_t *ids, int64_t n, uint8_t *
                       int8_t *current_player, void *stream) {
   if (!e || n < 0 || (!ids && n > e->d.batch)) return fail(TWX_E_ARG, "twx_status: bad argument");
   if (n == 0) return TWX_OK;
-  // (scalars are written by every launch: no materialisation needed)
+  // (no materialisation needed: the scalars follow from the stored ones and the journal records)
   TWX_USE(e);
+  if (int rc = refuse_capture(e, (hipStream_t)stream)) return rc;
   hipLaunchKernelGGL(status_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, e->state, e->d,
-                     ids, (long)n, result, move_counter, current_player);
+                     e->rolling ? twx::kJournalSlots : e->jpos, ids, (long)n, result, move_counter, current_player);
   HIP_TRY(hipGetLastError());
   return TWX_OK;
 }

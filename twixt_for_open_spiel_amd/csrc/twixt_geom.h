@@ -171,6 +171,11 @@ TWX_HD inline uint32_t policy_hash(uint32_t seed, uint32_t board, uint32_t episo
   return h;
 }
 
+// s1 of the stored scalars also carries the board's journal BASE in bits 16..19 while a journal
+// period runs: a board that was reset at journal position j owns only the records of slots >= j
+// (the older ones belong to its previous game and share their lines with other boards' records,
+// so they cannot be cleared one by one); every whole-board write outside a period stores base 0.
+constexpr int kJBaseShift = 16;
 // scalars after the move a journal record describes (move_counter, move_one, result, swapped:
 // tb.h:75-78 as Board::ApplyAction, tb.cc:457-499, leaves them); an empty record changes nothing
 TWX_HD inline void journal_scalars(uint32_t e, uint32_t &counter, uint32_t &move_one, uint32_t &result,

@@ -84,10 +84,10 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   auto batch_of = [&](long i) -> long { return (flags & kFlagReverse) ? (nbatch - 1 - i) : i; };
   auto tile_of = [&](long i) -> char * { return reinterpret_cast<char *>(state) + batch_of(i) * (long)(CHT * 512); };
 
-  // the last chunk (journal slots 4..7) is read only when a slot in it may hold a record (jpos > 4)
-  // or when the launch rewrites everything; otherwise its LDS row is zero-filled (slot 4 may be
-  // written, and the chunk is then stored)
-  const bool need_j2 = jpos > 4 || compact;
+  // a journal row (slots 0..3: chunk row CJ, the upper lane's half of pair W; slots 4..7: the odd
+  // tail) is read only when a slot in it holds a record of this period; nobody ever clears the
+  // rows: slots from jpos on hold stale records of older periods and are never looked at
+  const bool need_j1 = jpos > 0, need_j2 = jpos > 4;
   // ---- tile I/O (twixt_device_common.h): lane moves chunks 2j + h of board bl ----
   u32x4 nxt[NJ];
   uint32_t voff[NG];
@@ -103,9 +103,12 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   const uint32_t lds_lane = (uint32_t)(uintptr_t)((lds_u32 *)lds) + (uint32_t)h * 512u + (uint32_t)bl * 16u;
   auto load_slice = [&](auto c0t, auto c1t, const char *tile) {
     constexpr int c0 = decltype(c0t)::value, c1 = decltype(c1t)::value;
-    constexpr int c1r = (kOddTail && c1 == NJ) ? NJ - 1 : c1;  // regular chunks of this slice
+    static_assert(kOddTail && NJ == W + 2, "pairs 0..W-1: planes; pair W: scalars | journal row 0; tail: journal row 1");
+    constexpr int c1r = (c1 == NJ) ? NJ - 2 : c1;  // plane pairs of this slice
+    static_assert(c0 <= c1r, "the journal pairs belong to the last slice");
     pair_tile_load<c0, c1r>(nxt, voff, tile);
-    if constexpr (kOddTail && c1 == NJ) {
+    if constexpr (c1 == NJ) {
+      if (!up || need_j1) pair_tile_load_chunk<NJ - 2>(nxt[NJ - 2], voff[(NJ - 2) / 8], tile);
       if (!up && need_j2) pair_tile_load_chunk<NJ - 1>(nxt[NJ - 1], voff_tail, tile);
     }
   };
@@ -147,7 +150,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   uint32_t *const me = lds + (bl << 2);   // this board's slot inside every chunk row
   uint32_t *const meh = me + (up ? WH * GS : 0);  // first word group of this lane's half
   uint32_t *const sc = me + CS * RS;      // scalars
-  uint32_t *const jn = me + CJ * RS;      // journal slot s at jn[(s >> 2) * RS + (s & 3)]
+  const uint32_t *const jrow = lds + CJ * RS + bl;  // journal record s of this board: jrow[s * BPW] ([slot][board])
 
   STAMP_DECL;  // (diagnostic -DTWX_STAMPS build only: cycles per phase, tools/stamps.py)
   while (idx < nbatch) {
@@ -160,7 +163,6 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       asm volatile("" : "+v"(a_ext));  // the compiler's wait for this load belongs HERE, before the prefetch
     }
     pair_tile_fill<0, NJ>(lds_lane, nxt);
-    if (!need_j2 && !up) *reinterpret_cast<uint4 *>(lds + (bl << 2) + (CHT - 1) * RS) = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
     const char *const tile_next = tile_of((idx_next < nbatch) ? idx_next : idx);
     __builtin_amdgcn_sched_barrier(0);
@@ -182,10 +184,12 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     uint32_t episode = sv.z;
     // The stored scalars are as old as the planes: advance them by the journal records first
     // (slots 0..jpos-1, in order) -- the reset decision below needs the TRUE result.
+    uint32_t jbase = (sv.y >> twx::kJBaseShift) & 15u;  // first journal slot that belongs to this board's game
     uint32_t jr[twx::kJournalSlots];
-    {
-      const uint4 q0 = *reinterpret_cast<const uint4 *>(jn), q1 = *reinterpret_cast<const uint4 *>(jn + RS);
-      jr[0] = q0.x; jr[1] = q0.y; jr[2] = q0.z; jr[3] = q0.w; jr[4] = q1.x; jr[5] = q1.y; jr[6] = q1.z; jr[7] = q1.w;
+#pragma unroll
+    for (int s = 0; s < twx::kJournalSlots; s++) {
+      const uint32_t e = (s < jpos) ? jrow[s * BPW] : 0u;  // (wave-uniform; rows that were not loaded are not read)
+      jr[s] = ((uint32_t)s >= jbase) ? e : 0u;
     }
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++)
@@ -206,9 +210,9 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
                 make_uint4(0u, 0u, s_l ^ ((s_l ^ s_u) & hm), e_l ^ ((e_l ^ e_u) & hm));
           }
         }
-        *reinterpret_cast<uint4 *>(jn + h * RS) = make_uint4(0u, 0u, 0u, 0u);  // journal chunk h
 #pragma unroll
         for (int s = 0; s < twx::kJournalSlots; s++) jr[s] = 0u;  // nothing to replay on the empty board
+        jbase = (uint32_t)jpos;  // the records before this launch's slot belong to the finished game
         counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
       }
       wave_sync();
@@ -460,15 +464,13 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     STAMP(5);  // apply
     // scalars (s3 = the board's dirty mask during the flood below) and this move's record
     // (a board that was reset in a journalling launch is written whole with the scalars of the
-    // EMPTY board: its first move is in the record, and stored scalars + records = the truth)
-    *reinterpret_cast<uint4 *>(sc) = (was_reset && !compact)
-                                         ? make_uint4(0u, 0u, episode, 0u)
-                                         : make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
-    if (compact) {
-      *reinterpret_cast<uint4 *>(jn + h * RS) = make_uint4(0u, 0u, 0u, 0u);
-    } else {
-      jn[(jpos >> 2) * RS + (jpos & 3)] = entry;
-    }
+    // EMPTY board and its journal base: its first move is in the record, and stored scalars +
+    // records from the base on = the truth; a launch that rewrites everything stores base 0)
+    *reinterpret_cast<uint4 *>(sc) =
+        (was_reset && !compact)
+            ? make_uint4(0u, jbase << twx::kJBaseShift, episode, 0u)
+            : make_uint4(counter | (move_one << 16), result | (swapped << 8) | (compact ? 0u : jbase << twx::kJBaseShift),
+                         episode, 0u);
     wave_sync();
 
     // ---- ExploreLocalGraph (tb.cc:573-588), wave-cooperative, two boards per pass: lanes 0..31 on
@@ -560,15 +562,15 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       return reinterpret_cast<uint4 *>(tile_cur + ((uint32_t)bl * 16u + (uint32_t)c * 512u));
     };
     const bool wr = !(kAblate & 16);
-    if (compact) {
+    if (compact) {  // planes and scalars from LDS; the journal rows stay as they are (stale from now on)
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (wr && 2 * j + h < CHT) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
+        if (wr && 2 * j + h < CJ) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
     } else {
-      {  // the journal chunk of slot jpos: all a step normally writes (the record carries the scalars)
-        const int c = CJ + (jpos >> 2);
-        if (wr && !up) tile_store<true>(chunk_ptr(c), lds4[c * BPW + bl]);
-      }
+      // this move's record: all a step normally writes -- one dword per board, one 128-byte line
+      // per tile (the record carries the scalars)
+      if (wr && !up)
+        tile_store_word<true>(reinterpret_cast<uint32_t *>(tile_cur + CJ * 512 + jpos * (BPW * 4)) + bl, entry);
       STAMP(9);  // ticket + journal chunk store
       // flag chunks a flood fill changed (taking the first one along in the journal store's idle
       // upper lanes measured 1.9 % SLOWER: scattered lanes make that instruction expensive)
@@ -589,7 +591,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
         for (int j = 0; j < NJ; j++)
-          if (was_reset && wr && 2 * j + h < CHT) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
+          if (was_reset && wr && 2 * j + h < CJ) tile_store<true>(chunk_ptr(2 * j + h), lds4[(2 * j + h) * BPW + bl]);
       }
     }
     STAMP(11);  // reset boards / compaction

@@ -133,21 +133,26 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     const long t = (flags & kFlagReverse) ? (nbatch - 1 - i) : i;
     return reinterpret_cast<char *>(state) + t * (long)(CHT * 1024);
   };
-  // the second journal chunk (slots 4..7) is read only when a slot in it may hold a record:
-  // jpos > 4, or a launch that rewrites everything (its replay position may be anything under
-  // rolling compaction); otherwise its LDS row is zero-filled if slot 4 is about to be written
-  const bool need_j2 = twx::kJournalChunks != 2 || jpos_arg > 4 || (flags & (kFlagCompact | kFlagRolling)) != 0;
+  // A journal row (chunk row CJ: slots 0..3, CJ + 1: slots 4..7) is read only when a slot in it
+  // may hold a record of the running period (under rolling compaction a batch's position may be
+  // anything).  Outside rolling compaction nobody clears the rows: the slots from jpos on hold stale
+  // records of older periods and are never looked at.  Listed-boards launches (jpos = 0) skip them.
+  const bool rolling = (flags & kFlagRolling) != 0;
+  const bool need_j1 = rolling || jpos_arg > 0, need_j2 = rolling || jpos_arg > 4;
+  static_assert(twx::kJournalChunks == 2, "two journal rows");
+  constexpr int NL = SUB ? CJ : NJ;  // chunks a listed-boards launch moves
   if constexpr (FAST) {
-    tile_load<0, CHT - 1, AG, TS>(nxt, voff, tile_of(idx));
-    if (need_j2) tile_load<CHT - 1, CHT, AG, TS>(nxt, voff, tile_of(idx));
+    tile_load<0, CJ, AG, TS>(nxt, voff, tile_of(idx));
+    if (need_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_of(idx));
+    if (need_j2) tile_load<CJ + 1, CHT, AG, TS>(nxt, voff, tile_of(idx));
     vm_wait_all();  // first batch: nothing to overlap with
   } else {
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b0, TS, CHT)];
+    for (int j = 0; j < NL; j++) nxt[j] = gstate[chunk_index(chunk_of(j), b0, TS, CHT)];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
+    for (int j = 0; j < NL; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
   long idx_next = (dyn && nstatic == 1) ? ticket_batch(tv) : idx + gridDim.x;
   // Nothing the compiler tracks in its vmcnt bookkeeping may be consumed between the issue of the
@@ -164,7 +169,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // on MI355X than the burst (0.173 vs 0.158 ms per launch): kept as a tested option only.
   int jpos = jpos_arg;
   bool compact = compact_all;
-  if (flags & kFlagRolling) {
+  if (rolling) {
     const int period = (flags >> 8) & 15;
     const long tb = (flags & kFlagReverse) ? (nbatch - 1 - idx) : idx;
     // (+ tb / stride: a wave's successive batches tb, tb+stride, ... get different
@@ -186,12 +191,12 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   }
   if constexpr ((kAblate & 32) != 0) {
   } else if constexpr (FAST) {
-    tile_fill<0, CHT - 1, AG>(lds_lane, nxt);
-    if (need_j2) tile_fill<CHT - 1, CHT, AG>(lds_lane, nxt);
-    else *reinterpret_cast<uint4 *>(lds + (bl << 2) + (CHT - 1) * RS) = make_uint4(0u, 0u, 0u, 0u);
+    tile_fill<0, CJ, AG>(lds_lane, nxt);
+    if (need_j1) tile_fill<CJ, CJ + 1, AG>(lds_lane, nxt);
+    if (need_j2) tile_fill<CJ + 1, CHT, AG>(lds_lane, nxt);
   } else {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
+    for (int j = 0; j < NL; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
   }
   wave_sync();
   // prefetch of the next batch, issued in three slices between the phases below so
@@ -212,14 +217,16 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FAST) {
       if constexpr (c1 == NJ) {
-        tile_load<c0, c1 - 1, AG, TS>(nxt, voff, tile_next);
-        if (need_j2) tile_load<c1 - 1, c1, AG, TS>(nxt, voff, tile_next);
+        static_assert(c0 <= CJ, "the journal rows belong to the last slice");
+        tile_load<c0, CJ, AG, TS>(nxt, voff, tile_next);
+        if (need_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_next);
+        if (need_j2) tile_load<CJ + 1, CHT, AG, TS>(nxt, voff, tile_next);
       } else {
         tile_load<c0, c1, AG, TS>(nxt, voff, tile_next);
       }
     } else {
 #pragma unroll
-      for (int j = c0; j < c1; j++) nxt[j] = gstate[chunk_index((chunk_of(j) < CHT ? chunk_of(j) : CHT - 1), b1, TS, CHT)];
+      for (int j = c0; j < (c1 < NL ? c1 : NL); j++) nxt[j] = gstate[chunk_index(chunk_of(j), b1, TS, CHT)];
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -232,13 +239,19 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
 #ifdef TWX_SKELETON
   prefetch(Slice1{});
   prefetch(Slice2{});
-  const bool was_reset = false, terminal_on_entry = false; const uint32_t dirty = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
+  const bool was_reset = false, terminal_on_entry = false; const uint32_t dirty = 0u, rec = 0u; uint32_t result = 0, swapped = 0; bool illegal = false, act = true; int a = 0;
   { uint32_t *const sk = lds + (bl << 2) + 2 * G::W * RS; sk[0] += 1u; }
 #else
   uint32_t *const me = lds + (bl << 2);  // this board's slot inside every chunk row
   // word group i (cells 32i..32i+31) of this board: me + i * GS [+ plane_off(p)]
   uint32_t *const sc = me + CS * RS;     // scalars
-  uint32_t *const jn = me + CJ * RS;     // journal slot s at jn[(s >> 2) * RS + (s & 3)]
+  // journal record s of this board: [slot][board] dword rows inside the tile's journal area (a
+  // 64-board batch of 32-board tiles has two areas); subset launches (jpos = 0) never read it
+  // (the LDS image keeps the tiles of a batch side by side in every chunk row: slot s of the board in
+  // tile slot q sits at dword (s >> 2) * RS + tile * 4 TB + (s & 3) * TB + q of the journal rows)
+  constexpr int TB = 1 << TS;  // boards per tile
+  const uint32_t *const jrow = lds + CJ * RS + (bl >> TS) * (4 * TB) + (bl & (TB - 1));
+  auto jrec = [&](int s) -> uint32_t { return jrow[(s >> 2) * RS + (s & 3) * TB]; };
 
   const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
   uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
@@ -247,11 +260,12 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   bool was_reset = false;
   // The stored scalars are as old as the planes: advance them by the journal records first
   // (slots 0..jpos-1, in order) -- the reset decision below needs the TRUE result.
+  uint32_t jbase = (sv.y >> twx::kJBaseShift) & 15u;  // first journal slot that belongs to this board's game
   uint32_t jr[twx::kJournalSlots];
 #pragma unroll
-  for (int k = 0; k < twx::kJournalChunks; k++) {
-    const uint4 q = *reinterpret_cast<const uint4 *>(jn + k * RS);
-    jr[4 * k + 0] = q.x; jr[4 * k + 1] = q.y; jr[4 * k + 2] = q.z; jr[4 * k + 3] = q.w;
+  for (int s = 0; s < twx::kJournalSlots; s++) {
+    const uint32_t e = (s < jpos) ? jrec(s) : 0u;  // (wave-uniform guard: slots from jpos on are never replayed)
+    jr[s] = ((uint32_t)s >= jbase) ? e : 0u;
   }
 #pragma unroll
   for (int s = 0; s < twx::kJournalSlots - 1; s++)
@@ -265,8 +279,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       *reinterpret_cast<uint4 *>(me + i * GS + RS) =
           make_uint4(0u, 0u, G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
     }
-#pragma unroll
-    for (int k = 0; k < twx::kJournalChunks; k++) *reinterpret_cast<uint4 *>(jn + k * RS) = make_uint4(0u, 0u, 0u, 0u);
+    jbase = (uint32_t)jpos;  // the records before this launch's slot belong to the finished game
     counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
     was_reset = true;
   } else {
@@ -309,6 +322,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   int a = -1;
   bool act = false, illegal = false;
   uint32_t dirty = 0u;
+  uint32_t rec = 0u;  // journal record of this launch's move (single-step launches journal)
   // rsteps == 1: one env step.  rsteps > 1 (twx_random_rollout): up to rsteps moves per
   // board with the state staying in LDS, until every board of the batch is terminal.
   for (int rs = 0; rs < rsteps; rs++) {
@@ -496,16 +510,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   STAMP(5);  // apply: windows, crossing test, links, result
   // s3 is used below as the board's dirty mask (bit i: flag words of group i changed)
   // (a board that was reset in a journalling launch is written whole with the scalars of the
-  // EMPTY board: its first move is in the record, and stored scalars + records = the truth)
-  *reinterpret_cast<uint4 *>(sc) = (was_reset && !compact)
-                                       ? make_uint4(0u, 0u, episode, 0u)
-                                       : make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
-  if (compact) {
-#pragma unroll
-    for (int k = 0; k < twx::kJournalChunks; k++) *reinterpret_cast<uint4 *>(jn + k * RS) = make_uint4(0u, 0u, 0u, 0u);
-  } else {
-    jn[(jpos >> 2) * RS + (jpos & 3)] = entry;
-  }
+  // EMPTY board and its journal base: its first move is in the record, and stored scalars +
+  // records from the base on = the truth; a launch that rewrites everything stores base 0)
+  *reinterpret_cast<uint4 *>(sc) =
+      (was_reset && !compact)
+          ? make_uint4(0u, jbase << twx::kJBaseShift, episode, 0u)
+          : make_uint4(counter | (move_one << 16), result | (swapped << 8) | (compact ? 0u : jbase << twx::kJBaseShift),
+                       episode, 0u);
+  rec = entry;
   wave_sync();
 
   // ---- ExploreLocalGraph (tb.cc:573-588), wave-cooperative, two boards per pass:
@@ -612,14 +624,24 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       return state + chunk_index(c, board, TS, CHT);
   };
   if (compact) {
+    // planes and scalars from LDS.  The journal rows stay as they are (stale from now on); only
+    // rolling compaction, where a reader cannot know a batch's position, clears them
 #pragma unroll
-    for (int j = 0; j < NJ; j++)
-      if (wr && chunk_of(j) < CHT) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
+    for (int j = 0; j < NJ; j++) {
+      if (wr && chunk_of(j) < CJ) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
+      if (FAST && rolling && wr && chunk_of(j) >= CJ && chunk_of(j) < CHT)
+        tile_store<NT>(chunk_ptr(chunk_of(j)), make_uint4(0u, 0u, 0u, 0u));
+    }
   } else {
-    // the journal chunk of slot jpos: all a step normally writes (the record carries the scalars)
-    const int jc = CJ + (jpos >> 2);
-    if (wr && half == 0) tile_store<NT>(chunk_ptr(jc), lds4[jc * BPW + bl]);
-    STAMP(9);  // fixed store (journal chunk)
+    // this move's record: all a step normally writes -- one dword per board, a contiguous line per
+    // tile (the record carries the scalars).  Only whole-batch launches journal.
+    if constexpr (FAST) {
+      if (wr)
+        tile_store_word<NT>(reinterpret_cast<uint32_t *>(tile_cur + (uint32_t)(lane >> TS) * (uint32_t)(CHT * RB) +
+                                                         (uint32_t)(CJ * RB) + (uint32_t)jpos * (4u << TS)) + (lane & ((1 << TS) - 1)),
+                            rec);
+    }
+    STAMP(9);  // fixed store (journal record)
     // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
     // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
     uint32_t dd = (was_reset || !wr || half || (kAblate & 2)) ? 0u : dirty;
@@ -634,7 +656,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && chunk_of(j) < CHT) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
+        if (was_reset && chunk_of(j) < CJ) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
     }
   }
   STAMP(11);  // reset lanes / compaction

@@ -69,7 +69,7 @@ __global__ void import_kernel(uint4 *state, Dims d, const int32_t *ids, long n, 
     v.z = src[(p0 + 2) * d.W + i]; v.w = src[(p0 + 3) * d.W + i];
   } else {
     const uint32_t *sc = src + twx::kNumPlanes * d.W;
-    v.x = sc[0]; v.y = sc[1]; v.z = sc[2]; v.w = sc[3];
+    v.x = sc[0]; v.y = sc[1] & ~(15u << twx::kJBaseShift); v.z = sc[2]; v.w = sc[3];  // (journal base: an internal field)
   }
   state[chunk_index(c, b, d.ts, d.CHT)] = v;
 }
@@ -110,7 +110,7 @@ __global__ void legal_mask_kernel(const uint4 *state, Dims d, const uint32_t *re
   }
 }
 
-__global__ void status_kernel(const uint4 *state, Dims d, const int32_t *ids, long n, uint8_t *result,
+__global__ void status_kernel(const uint4 *state, Dims d, int jpos, const int32_t *ids, long n, uint8_t *result,
                               int32_t *move_counter, int8_t *current_player) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -118,14 +118,13 @@ __global__ void status_kernel(const uint4 *state, Dims d, const int32_t *ids, lo
   if (b < 0 || b >= d.batch) return;
   const uint4 s = state[chunk_index((d.CH - 1), b, d.ts, d.CHT)];
   uint32_t counter = s.x & 0xffffu, res = s.y & 0xffu, move_one = s.x >> 16, swapped = (s.y >> 8) & 1u;
-  // the stored scalars are as old as the planes: advance them by the journal (empty slots are zero)
-  for (int k = 0; k < twx::kJournalChunks; k++) {
-    const uint4 jr = state[chunk_index(d.CH + k, b, d.ts, d.CHT)];
-    twx::journal_scalars(jr.x, counter, move_one, res, swapped);
-    twx::journal_scalars(jr.y, counter, move_one, res, swapped);
-    twx::journal_scalars(jr.z, counter, move_one, res, swapped);
-    twx::journal_scalars(jr.w, counter, move_one, res, swapped);
-  }
+  // the stored scalars are as old as the planes: advance them by the board's journal records
+  // ([slot][board] rows) from the board's base slot up to the handle's journal position (the
+  // slots above hold stale records; rolling compaction passes kJournalSlots: its empty slots are zero)
+  const uint32_t *const words = reinterpret_cast<const uint32_t *>(state);
+  const int jbase = (int)((s.y >> twx::kJBaseShift) & 15u);
+  for (int sl = jbase; sl < jpos; sl++)
+    twx::journal_scalars(words[journal_word_index(sl, b, d.ts, d.CHT)], counter, move_one, res, swapped);
   if (result) result[j] = (uint8_t)res;
   if (move_counter) move_counter[j] = (int32_t)counter;
   if (current_player) current_player[j] = res ? (int8_t)-4 : (int8_t)(counter & 1u);  // tw.h:99-103
