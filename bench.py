@@ -40,8 +40,7 @@ TRAFFIC_FILE = os.path.join("profiles", "traffic_step_kernel_n24.json")
 def journal_period(n):
     """twixt_engine.hip default_period(): launches between two whole-board writes."""
     w = (n * n + 31) // 32
-    return 1 if w <= 2 else 2 if w == 3 else 4 if w <= 7 else 8
-
+    return 1 if w <= 3 else 2 if w <= 5 else 4 if w <= 10 else 8
 
 
 def algo_bytes(n):
@@ -58,15 +57,15 @@ def step_kernel_name(n):
 
 def design_bytes(n):
     """Bytes this design moves per env step by construction, journal period
-    P = journal_period(n): every launch reads the board's CHT = 2W+3 chunks of 16 B (the big
-    boards' kernel skips the second journal chunk while it cannot hold a record: 5 launches in 8);
-    P-1 launches in P write one journal chunk (16 B: the record carries the scalars), the P-th
-    rewrites all CHT chunks.  (Flag chunks a multi-cell flood fill dirtied and auto-reset boards
-    add a few bytes.)"""
-    cht = 2 * ((n * n + 31) // 32) + 3
+    P = journal_period(n): every launch reads the board's CH = 2W+1 chunks of 16 B (planes and
+    scalars) and the journal rows that hold records of the running period (16 B per board each:
+    row 0 from the second launch of a period on, row 1 from the sixth); P-1 launches in P write one
+    journal record (4 B: it carries the scalars), the P-th rewrites the CH chunks.  (Flag chunks a
+    multi-cell flood fill dirtied and auto-reset boards add a few bytes.)"""
+    ch = 2 * ((n * n + 31) // 32) + 1
     p = journal_period(n)
-    read = 16.0 * cht - (16.0 * 5 / 8 if cht > 25 else 0.0)
-    return read + ((p - 1) * 16.0 + 16.0 * cht) / p
+    rows = sum((j > 0) + (j > 4) for j in range(p))
+    return 16.0 * ch + 16.0 * rows / p + ((p - 1) * 4.0 + 16.0 * ch) / p
 
 
 def host_cores():

@@ -203,12 +203,13 @@ struct twx_env {
 namespace {
 
 // Journal period by board size (launches between two whole-board writes; measured at B = 2^20,
-// tools/sweep_small.sh): the journal trades write bytes for replay work, which pays where the
-// board stream is the bound.  N <= 8 (bound by the integer work, 112 B of state) rewrite the planes
-// every step, N = 9 every second, N = 10..14 every fourth, larger boards every eighth step.
+// tools/sweep_small.sh, profiles/r02_small_board_period_sweep.txt): the journal trades write bytes
+// for replay work, which pays where the board stream is the bound.  N <= 9 (bound by the integer
+// work, at most 112 B of state) rewrite the planes every step, N = 10..12 every second, N = 13..17
+// every fourth, larger boards every eighth step.
 int default_period(int n) {
   const int W = twx::plane_words(n);
-  const int p = W <= 2 ? 1 : W == 3 ? 2 : W <= 7 ? 4 : 8;
+  const int p = W <= 3 ? 1 : W <= 5 ? 2 : W <= 10 ? 4 : 8;
   return p < twx::kJournalSlots ? p : twx::kJournalSlots;
 }
 
