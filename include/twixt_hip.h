@@ -23,13 +23,14 @@
  *     ordered by that stream).  Between compactions the board state is log-structured
  *     (DESIGN.md): the step functions carry a host-side journal position as a launch
  *     argument, so a sequence of steps must not be replayed from a captured hipGraph
- *     (the step functions return TWX_E_ARG on a capturing stream)
+ *     (the step functions and twx_status / twx_status_boards, which read the journal up
+ *     to that position, return TWX_E_ARG on a capturing stream)
  *     unless the handle was created with TWX_GRAPH_SAFE=1 in the environment (planes
  *     rewritten in place every step, fixed batch order: every launch argument is then
  *     constant; meant for small, launch-bound batches such as search leaves);
  *     every other entry point first materialises the journal and is unaffected.
  *   - tuning knobs read once by twx_create from the environment: TWX_JOURNAL_PERIOD
- *     (1..8; default by board size: 1 for N <= 8, 2 for N = 9, 4 for N = 10..14, 8 above;
+ *     (1..8; default by board size: 1 for N <= 9, 2 for N = 10..12, 4 for N = 13..17, 8 above;
  *     1 = rewrite the planes every step), TWX_PAIR (0/1, default 1: whole-batch steps of
  *     N >= 19 run the two-lanes-per-board kernel), TWX_PINGPONG (0/1, default 1:
  *     alternate the batch order between launches), TWX_WAVES_PER_CU (default: occupancy),
@@ -48,6 +49,7 @@
  * followed by 4 scalar dwords:
  *   s0 = move_counter | move_one_action << 16                  (tb.h:75-77)
  *   s1 = result | swapped << 8                                 (tb.h:76,78)
+ *        (bits 16..19 are internal: exported as 0, ignored on import)
  *   s2 = episode (number of auto-resets, feeds the policy hash)
  *   s3 = 0 (reserved)
  * twx_state_words(N) = 8*W + 4.  twx_export_state / twx_import_state use this
