@@ -289,6 +289,49 @@ def test_full_size_every_board(torch_mod):
     env.close()
 
 
+def test_four_million_boards_past_2gib(torch_mod):
+    """A maximum-size case: N=24 with 2^22 + 37 boards is a 2.6 GB state array, so tiles lie on both
+    sides of byte offset 2^31 (64-bit tile addressing), the batch is ragged, and the shard sits
+    right below the 2^32 limit of the board-id range.  20 auto-reset steps; the first, the last and
+    the boards around the 2 GiB mark are compared bit-for-bit, every board by the peg-count law."""
+    import oracle_binding as ob
+    torch = torch_mod
+    n, batch, steps, seed = 24, (1 << 22) + 37, 20, 6
+    first = (1 << 32) - batch                       # first_board_id + batch == 2^32: the last id allowed
+    env = make_env(n, batch, first=first)
+    stat = None
+    for _ in range(steps):
+        _, stat = env.step_random(seed, True, want_actions=False)
+    torch.cuda.synchronize()
+    stat = stat.cpu().numpy()
+    mid = (1 << 31) // (39 * 16)                    # the board whose tile straddles byte 2^31 (39 chunks of 16 B)
+    for lo, cnt in ((0, 4096), (mid - 2048, 4096), (batch - 4096 - 37, 4096 + 37)):
+        ref = ob.rollout_batch(n, seed, first + lo, cnt, steps, True, want_trace=True)
+        got = u32(env.export_state(torch.arange(lo, lo + cnt, dtype=torch.int32)))
+        sw = got.shape[1]
+        assert np.array_equal(got[:, :sw - 1], ref["planes"][:, :sw - 1]), "boards %d..%d" % (lo, lo + cnt)
+        assert np.array_equal(stat[lo:lo + cnt], ref["status"][:, -1]), "status %d..%d" % (lo, lo + cnt)
+    res, mc, _ = env.status()
+    assert int(mc.min()) == steps and int(mc.max()) == steps and not res.any()   # nobody finishes in 20 moves
+    W = env.mask_words
+    pegs = torch.zeros(batch, dtype=torch.int64, device=res.device)
+    for lo in range(0, batch, 1 << 20):             # (export in slices: the whole state is 2.5 GB of words)
+        ids = torch.arange(lo, min(lo + (1 << 20), batch), dtype=torch.int32)
+        st = env.export_state(ids)
+        rb = st[:, :2 * W].to(torch.int64) & 0xffffffff
+        c = torch.zeros(rb.shape[0], dtype=torch.int64, device=rb.device)
+        for k in range(32):
+            c += ((rb >> k) & 1).sum(dim=1)
+        swapped = (st[:, 8 * W + 1].to(torch.int64) >> 8) & 1
+        pegs[lo:lo + rb.shape[0]] = c + swapped
+    assert int(pegs.min()) == steps and int(pegs.max()) == steps
+    env.close()
+    from twixt_for_open_spiel_amd import TwixtBatchEnv
+    from twixt_for_open_spiel_amd._lib import TwixtHipError
+    with pytest.raises(TwixtHipError):               # one id too many
+        TwixtBatchEnv(n, 64, 0, (1 << 32) - 63)
+
+
 @pytest.mark.parametrize("period,pingpong,rolling", [(1, 0, 1), (2, 1, 0), (3, 0, 1), (5, 1, 0), (8, 0, 0), (8, 1, 1),
                                                      (4, 1, 1), (8, 0, 1)])
 def test_journal_periods(torch_mod, period, pingpong, rolling, monkeypatch):

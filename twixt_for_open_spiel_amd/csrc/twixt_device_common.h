@@ -11,7 +11,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte v
 //   chunk 2i   = { red_i, blue_i, linkNNE_i, linkENE_i }      i = 0..W-1
 //   chunk 2i+1 = { linkESE_i, linkSSE_i, start_i, end_i }
 //   chunk 2W   = scalars { s0, s1, s2, s3 }
-//   chunk 2W+1, 2W+2 = redo journal, 8 x 32-bit records
+//   chunk rows 2W+1, 2W+2 of a tile = redo journal, 8 slots x boards of the tile x 32-bit records
+//   ([slot][board], journal_word_index() below)
 // i.e. the 8 planes are interleaved word by word: everything about the 32 cells
 // 32i..32i+31 sits in two adjacent chunks.  One address computation per cell /
 // column then reaches every plane through immediate offsets.
@@ -21,6 +22,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native 16-byte v
 
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_or_b32
+}
+// two adjacent dwords (p 8-byte aligned) in one LDS operation
+__device__ __forceinline__ void lds_or2(uint32_t *p, uint32_t v0, uint32_t v1) {
+  __hip_atomic_fetch_or(reinterpret_cast<uint64_t *>(p), (uint64_t)v0 | ((uint64_t)v1 << 32), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_or_b64
 }
 __device__ __forceinline__ void lds_and(uint32_t *p, uint32_t v) {
   __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // ds_and_b32

@@ -12,7 +12,7 @@
 //   Both: a persistent wave streams its boards (CHT 16-byte chunks each, tiles
 //   of the state array, twixt_device_common.h) into LDS with coalesced 1 KiB
 //   loads prefetched a batch ahead, works on them there, and writes back one
-//   journal chunk per board -- the state is log-structured;
+//   32-bit journal record per board -- the state is log-structured;
 //   legal mask + k-th-legal-action pick are whole-plane popcount scans; the
 //   8-direction link scan and the 72 crossing probes are constant-mask tests on
 //   a 5x7 window of the link planes (twixt_geom.h kCross); the border-flag
@@ -66,43 +66,33 @@ int fail(int code, const std::string &msg) {
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                       const int32_t *ids, long nsub, int rsteps, int bpw, uint32_t *ticket, TicketBases ticket_base,
+                       const int32_t *ids, long nsub, int rsteps, uint32_t *ticket, TicketBases ticket_base,
                        int nstatic, hipStream_t s) {
-  const long nbatch = ids ? (nsub + bpw - 1) / bpw : bpad / bpw;
+  const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
-  const size_t rows = (bpw == 64) ? twx::Geo<N>::CHT : 2 * ((twx::Geo<N>::CHT + 1) / 2);
-  const size_t lds_bytes = rows * bpw * 16;  // 39 KiB at N=24
+  const size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // the wave's 64 boards: 39 KiB at N=24
 #define TWX_LAUNCH(K)                                                                                      \
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
                      actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, ticket, ticket_base, nstatic)
-  if (bpw == 64) {
-    if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT) {
-      if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
-    } else {
-      if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
-    }
+  if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT) {
+    if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
   } else {
-    return hipErrorInvalidConfiguration;
+    if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
   }
 #undef TWX_LAUNCH
   return hipGetLastError();
 }
 
-// resident waves per CU of the whole-batch kernel for this N (LDS image + registers)
+// resident waves per CU of the whole-batch one-lane-per-board kernel for this N (LDS image + registers)
 template <int N>
-int step_occupancy(int bpw) {
-  const size_t rows = (bpw == 64) ? twx::Geo<N>::CHT : 2 * ((twx::Geo<N>::CHT + 1) / 2);
-  const size_t lds_bytes = rows * bpw * 16;
+int step_occupancy() {
+  const size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;
   int blocks = 0;
   hipError_t e;
-  if (bpw == 64) {
-    if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64_small<N, false>, kWave, lds_bytes);
-    else
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64<N, false>, kWave, lds_bytes);
-  } else {
-    e = hipErrorInvalidConfiguration;
-  }
+  if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64_small<N, false>, kWave, lds_bytes);
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_kernel64<N, false>, kWave, lds_bytes);
   return (e == hipSuccess && blocks > 0) ? blocks : 0;
 }
 
@@ -135,15 +125,13 @@ int pair_occupancy() {
 typedef hipError_t (*pair_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t, int, int,
                               int, uint32_t *, TicketBases, int, hipStream_t);
 
-typedef int (*wocc_fn)();
-
-typedef int (*occ_fn)(int);
+typedef int (*occ_fn)();
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, const int32_t *, long, int, int, uint32_t *, TicketBases, int, hipStream_t);
+                              int, int, int, const int32_t *, long, int, uint32_t *, TicketBases, int, hipStream_t);
 
 template <int N>
 struct StepTable {
-  static void fill(step_fn *t, occ_fn *o, pair_fn *p, wocc_fn *po) {
+  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po) {
     t[N] = &launch_step<N>;
     o[N] = &step_occupancy<N>;
     p[N] = &launch_pair<N>;
@@ -153,14 +141,14 @@ struct StepTable {
 };
 template <>
 struct StepTable<TWX_MIN_BOARD_SIZE - 1> {
-  static void fill(step_fn *, occ_fn *, pair_fn *, wocc_fn *) {}
+  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *) {}
 };
 
 struct StepTables {
   step_fn step[TWX_MAX_BOARD_SIZE + 1];
   occ_fn occ[TWX_MAX_BOARD_SIZE + 1];
   pair_fn pair[TWX_MAX_BOARD_SIZE + 1];
-  wocc_fn pocc[TWX_MAX_BOARD_SIZE + 1];
+  occ_fn pocc[TWX_MAX_BOARD_SIZE + 1];
   StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc); }
 };
 const StepTables &step_tables() {
@@ -188,7 +176,6 @@ struct twx_env {
   bool pingpong;
   uint64_t launches;
   int waves;  // persistent grid: resident waves = CUs x waves the LDS image admits per CU
-  int bpw;    // boards per wave: 64 or 32 (TWX_BOARDS_PER_WAVE)
   int init_off;    // word offset of the initial-position chunks inside `tables`
   bool pair;       // whole-batch launches go to step_pair_kernel (two lanes per board; big boards)
   int waves_pair;  // its persistent grid
@@ -284,7 +271,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   {
     // whole-batch launches of the big boards: the two-lanes-per-board kernel
     const bool use_pair = e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling);
-    const int bpw = use_pair ? 32 : e->bpw, waves = use_pair ? e->waves_pair : e->waves;
+    const int bpw = use_pair ? 32 : kWave, waves = use_pair ? e->waves_pair : e->waves;  // boards per wave
     // dynamic tail: the groups need equal numbers of waves, and there must be batches beyond
     // the first round; by default the last eighth of the rounds (at least two) is dynamic
     const long nbatch = ids ? (nsub + bpw - 1) / bpw : e->d.bpad / bpw;
@@ -309,7 +296,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
                                          (int)nstatic, s));
     else
       HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                               (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->bpw, e->ticket,
+                               (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->ticket,
                                e->ticket_base, (int)nstatic, s));
     if (dyn) {
       // group g: its dynamic batches (idx >= nstatic * grid, idx % groups == g) + two draws per
@@ -432,15 +419,14 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->ticket = nullptr;
   e->ticket_base = TicketBases{};
   {
-    e->bpw = 64;
     // as many waves as are resident at once (LDS image and registers; 4 per CU at N=24,
     // 8 at N=12, 12 at N=8): each walks its share of the batches
-    int per_cu = step_tables().occ[n](e->bpw);
+    int per_cu = step_tables().occ[n]();
     if (per_cu < 1) per_cu = 4;
     if (per_cu > 16) per_cu = 16;
     e->waves = (cus > 0 ? cus : 256) * env_int("TWX_WAVES_PER_CU", per_cu, 1, 32);
     const int pocc = step_tables().pocc[n]();
-    e->pair = pocc > 0 && e->bpw == 64 && env_int("TWX_PAIR", 1, 0, 1) != 0;
+    e->pair = pocc > 0 && env_int("TWX_PAIR", 1, 0, 1) != 0;
     e->waves_pair = (cus > 0 ? cus : 256) * env_int("TWX_PAIR_WAVES_PER_CU", pocc > 0 ? pocc : 1, 1, 32);
   }
   e->d.batch = batch;

@@ -236,8 +236,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         lds_or(g + offA + (int)((e >> 10) & pm), bit & ((uint32_t)sbit(e, 19) | ~hm));
         lds_or(g + oE, bit & (uint32_t)sbit(e, 20) & hm);  // upper: END gained
         const uint32_t eo = e >> own_sh;  // bits 0, 1: this lane's links at the cell; bits 4, 5: at the targets
-#pragma unroll
-        for (int j = 0; j < 2; j++) lds_or(g + link_lo + j, bit & (uint32_t)sbit(eo, j));
+        lds_or2(g + link_lo, bit & (uint32_t)sbit(eo, 0), bit & (uint32_t)sbit(eo, 1));
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const uint32_t on = (uint32_t)sbit(eo, 4 + j);
@@ -438,8 +437,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       {  // tb.cc:532-533: one stored bit per physical link, at its west end; lower lane links 0, 1
          // (west end = the new peg) and 4, 5 (west end = the target), upper lane 2, 3 and 6, 7
         const uint32_t lo = linkm >> (2 * h);
-#pragma unroll
-        for (int j = 0; j < 2; j++) lds_or(gp + link_lo + j, pbit & (uint32_t)sbit(lo, j));
+        lds_or2(gp + link_lo, pbit & (uint32_t)sbit(lo, 0), pbit & (uint32_t)sbit(lo, 1));
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const uint32_t on = (uint32_t)sbit(lo, 4 + j);
@@ -571,9 +569,10 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       // per tile (the record carries the scalars)
       if (wr && !up)
         tile_store_word<true>(reinterpret_cast<uint32_t *>(tile_cur + CJ * 512 + jpos * (BPW * 4)) + bl, entry);
-      STAMP(9);  // ticket + journal chunk store
-      // flag chunks a flood fill changed (taking the first one along in the journal store's idle
-      // upper lanes measured 1.9 % SLOWER: scattered lanes make that instruction expensive)
+      STAMP(9);  // ticket + journal record store
+      // flag chunks a flood fill changed (taking the first one along in the idle upper lanes of the
+      // journal store -- then a 16-byte chunk per board -- measured 1.9 % SLOWER: scattered lanes make
+      // that instruction expensive)
       uint32_t dd = (was_reset || !wr || (kAblate & 2)) ? 0u : dirty;
       // ... every dirty board walks its own mask, two chunks per trip (lower lane the lowest dirty
       // group, upper lane the next one)

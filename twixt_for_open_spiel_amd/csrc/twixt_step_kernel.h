@@ -1,4 +1,4 @@
-// twixt_step_kernel.h -- step_body<N,SUB,BPW> and its __global__ wrappers: the fused env step (hot path)
+// twixt_step_kernel.h -- step_body<N,SUB> and its __global__ wrappers: the fused env step, one lane per board
 // Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
 #ifndef TWIXT_STEP_KERNEL_H_
 #define TWIXT_STEP_KERNEL_H_
@@ -9,11 +9,11 @@
 // Log-structured state: between two compactions a launch does not
 // rewrite the planes; it appends one 32-bit record of the move to the board's
 // journal (slot `jpos`, the same for every board) and writes back only that
-// journal chunk: the record carries the scalars and the single-cell fills
-// (twixt_geom.h).  The next launches replay slots 0..jpos-1 on top of the planes
-// they stream in.  Every `period`-th launch (kFlagCompact) writes everything and
-// clears the journal.  Lanes that auto-reset write their whole board; lanes whose
-// multi-cell flood fill changed flag words write those chunks.
+// record: it carries the scalars and the single-cell fills (twixt_geom.h).  The
+// next launches replay slots 0..jpos-1 on top of the planes they stream in.  Every
+// `period`-th launch (kFlagCompact) writes planes and scalars and starts a new
+// period.  Lanes that auto-reset write their whole board; lanes whose multi-cell
+// flood fill changed flag words write those chunks.
 // Diagnostic builds only (-DTWX_ABLATE=mask, tools/README.md): leave a phase out to measure what
 // it really costs inside the overlapped loop (results are then wrong by construction).
 //   1 flood fill   2 dirty-chunk stores   4 journal replay (the planes' part; the scalars still advance)
@@ -24,7 +24,7 @@
 #endif
 constexpr int kAblate = TWX_ABLATE;
 
-template <int N, bool SUB, int BPW>
+template <int N, bool SUB>
 __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, long batch,
                                                      const int32_t *__restrict__ actions,
                                                      int32_t *__restrict__ actions_out,
@@ -36,23 +36,21 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   using G = twx::Geo<N>;
   const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
   constexpr int W = G::W, CS = 2 * W, CJ = 2 * W + 1, CHT = G::CHT;
-  // BPW boards per wave (64: one per lane; 32: both 32-lane halves run the same per-board
-  // logic on the same board -- every LDS update is an idempotent OR / AND / equal-value
-  // store -- while fills, prefetches and stores are split by half: the LDS image is half
-  // as big, so 8 waves fit a CU instead of 4).  RS = dwords per chunk row of the image.
-  static_assert(BPW == 64 || BPW == 32, "boards per wave");
-  constexpr int RS = BPW * 4, GS = 2 * RS;  // chunk-row / word-group stride in dwords
-  constexpr int NJ = (BPW == 64) ? CHT : (CHT + 1) / 2;  // 16-byte registers a lane prefetches
+  constexpr int BPW = kWave;                // boards per wave: one per lane
+  constexpr int RS = BPW * 4, GS = 2 * RS;  // chunk-row / word-group stride of the LDS image in dwords
+  constexpr int NJ = CHT;                   // 16-byte registers a lane prefetches
 #define plane_off(p) ((((p) >> 2) * RS) + ((p) & 3))
   constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
                 oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
   constexpr uint32_t kColMask = (1u << N) - 1u;
+  static_assert(oE == oS + 1 && (oS & 1) == 0 && (plane_off(twx::kPlaneLink0) & 1) == 0 && (plane_off(twx::kPlaneLink0 + 2) & 1) == 0,
+                "lds_or2 pairs: adjacent, 8-byte aligned planes");
   static_assert(CHT == 2 * W + 1 + twx::kJournalChunks && W <= 32, "layout");
   // whole-batch launches on the tiled layout address a batch as one contiguous tile and keep
   // the prefetched batch in AGPRs (big boards: one wave per SIMD owns all 512 registers)
   constexpr int TS = tile_shift(CHT);         // boards per tile of the state array: 64, or 32 for N >= 19
   constexpr int RB = 16 << TS;                // bytes of a chunk row of a tile
-  constexpr bool FAST = !SUB && BPW == 64;
+  constexpr bool FAST = !SUB;
   constexpr bool AG = FAST && CHT > TWX_SMALL_CHT;
   constexpr bool NT = CHT > TWX_PLAIN_STORE_CHT;  // non-temporal write-back where the board stream is the bound
   constexpr int NG = (CHT * RB + 8191) / 8192;  // per-lane offset registers: one per 8 KiB of a tile
@@ -60,9 +58,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   uint4 *lds4 = reinterpret_cast<uint4 *>(lds);
 
   const int lane = threadIdx.x;
-  const int half = (BPW == 64) ? 0 : (lane >> 5);  // which chunk parity this lane moves
-  const int bl = lane & (BPW - 1);                 // board slot of this lane inside the batch
-  auto chunk_of = [&](int j) -> int { return (BPW == 64) ? j : 2 * j + half; };
+  const int bl = lane;  // board slot of this lane inside the batch
   const bool compact_all = (flags & kFlagCompact) != 0;
   const bool flush = (flags & kFlagFlush) != 0;
   const bool random = (flags & kFlagRandom) != 0;
@@ -150,7 +146,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
-    for (int j = 0; j < NL; j++) nxt[j] = gstate[chunk_index(chunk_of(j), b0, TS, CHT)];
+    for (int j = 0; j < NL; j++) nxt[j] = gstate[chunk_index(j, b0, TS, CHT)];
 #pragma unroll
     for (int j = 0; j < NL; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
@@ -196,7 +192,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     if (need_j2) tile_fill<CJ + 1, CHT, AG>(lds_lane, nxt);
   } else {
 #pragma unroll
-    for (int j = 0; j < NL; j++) ldsv[j * kWave + lane] = nxt[j];  // row chunk_of(j), slot bl
+    for (int j = 0; j < NL; j++) ldsv[j * kWave + lane] = nxt[j];  // row j, slot bl
   }
   wave_sync();
   // prefetch of the next batch, issued in three slices between the phases below so
@@ -226,7 +222,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       }
     } else {
 #pragma unroll
-      for (int j = c0; j < (c1 < NL ? c1 : NL); j++) nxt[j] = gstate[chunk_index(chunk_of(j), b1, TS, CHT)];
+      for (int j = c0; j < (c1 < NL ? c1 : NL); j++) nxt[j] = gstate[chunk_index(j, b1, TS, CHT)];
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -293,24 +289,22 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
         uint32_t *const g = me + (cell >> 5) * GS;
         if (e & (1u << 21)) lds_and(me + (move_one >> 5) * GS + oR, ~(1u << (move_one & 31)));  // swap: tb.cc:450-455
         lds_or(g + oR + ((e >> 10) & 1u), bit);  // peg: red / blue words are adjacent
-#pragma unroll
-        for (int d = 0; d < 4; d++)  // links whose west end is this peg
-          lds_or(g + oL0 + plane_off(twx::kPlaneLink0 + d) - oL0, (e & (1u << (11 + d))) ? bit : 0u);
+        // links whose west end is this peg: planes 2, 3 and 4, 5 are adjacent dword pairs
+        lds_or2(g + plane_off(twx::kPlaneLink0), (e & (1u << 11)) ? bit : 0u, (e & (1u << 12)) ? bit : 0u);
+        lds_or2(g + plane_off(twx::kPlaneLink0 + 2), (e & (1u << 13)) ? bit : 0u, (e & (1u << 14)) ? bit : 0u);
 #pragma unroll
         for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
           const bool on = (e & (1u << (11 + d))) != 0u;
           const int tc = on ? cell + twx::kDX[d] * N + twx::kDY[d] : cell;
           lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
         }
-        lds_or(g + oS, (e & (1u << 19)) ? bit : 0u);
-        lds_or(g + oE, (e & (1u << 20)) ? bit : 0u);
+        lds_or2(g + oS, (e & (1u << 19)) ? bit : 0u, (e & (1u << 20)) ? bit : 0u);  // START | END gained
         {  // the single neighbour a fill flagged (the record carries its direction)
           const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
           const bool on = (e & (twx::kJFillStart | twx::kJFillEnd)) != 0u;
           const int t = on ? cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2 : cell;
           uint32_t *const gt = me + (t >> 5) * GS;
-          lds_or(gt + oS, (e & twx::kJFillStart) ? (1u << (t & 31)) : 0u);
-          lds_or(gt + oE, (e & twx::kJFillEnd) ? (1u << (t & 31)) : 0u);
+          lds_or2(gt + oS, (e & twx::kJFillStart) ? (1u << (t & 31)) : 0u, (e & twx::kJFillEnd) ? (1u << (t & 31)) : 0u);
         }
       }
     }
@@ -471,8 +465,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       }
       if (!(other & 1u)) {
         const uint32_t tbit = 1u << (t & 31);
-        lds_or(gt + oS, (want & 1u) ? tbit : 0u);
-        lds_or(gt + oE, (want & 2u) ? tbit : 0u);
+        lds_or2(gt + oS, (want & 1u) ? tbit : 0u, (want & 2u) ? tbit : 0u);
         // persisted by this move's journal record (or by the whole-board write of this launch)
         fill1 = ((uint32_t)d << twx::kJFillDirShift) | ((want & 1u) ? twx::kJFillStart : 0u) |
                 ((want & 2u) ? twx::kJFillEnd : 0u);
@@ -483,16 +476,15 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     {  // tb.cc:532-533: one stored bit per physical link, at its west end
       uint32_t *const g = me + (pa >> 5) * GS;
       const uint32_t bit = 1u << (pa & 31);
-#pragma unroll
-      for (int d = 0; d < 4; d++) lds_or(g + plane_off(twx::kPlaneLink0 + d), (linkm & (1u << d)) ? bit : 0u);
+      lds_or2(g + plane_off(twx::kPlaneLink0), (linkm & 1u) ? bit : 0u, (linkm & 2u) ? bit : 0u);
+      lds_or2(g + plane_off(twx::kPlaneLink0 + 2), (linkm & 4u) ? bit : 0u, (linkm & 8u) ? bit : 0u);
 #pragma unroll
       for (int d = 4; d < 8; d++) {
         const bool on = (linkm & (1u << d)) != 0u;
         const int tc = on ? pa + twx::kDX[d] * N + twx::kDY[d] : pa;
         lds_or(me + (tc >> 5) * GS + plane_off(twx::kPlaneLink0 + d - 4), on ? (1u << (tc & 31)) : 0u);
       }
-      lds_or(g + oS, gain_s ? bit : 0u);
-      lds_or(g + oE, gain_e ? bit : 0u);
+      lds_or2(g + oS, gain_s ? bit : 0u, gain_e ? bit : 0u);
       if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
       counter += 1u;
       // ---- UpdateResult (tb.cc:192-207) ----
@@ -526,7 +518,6 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   //      flag plane.  Frontier expansion: columns move by DPP wave shifts (1 VALU
   //      op each), rows by bit shifts; stop when no half found a new cell. ----
   uint64_t todo = __ballot(pend != 0u);
-  if (BPW == 32) todo &= 0xffffffffull;  // the upper half mirrors the lower one
   if (kAblate & 1) todo = 0ull;
   while (todo) {
     const int s0 = (int)__ffsll((unsigned long long)todo) - 1;
@@ -615,7 +606,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
 
   STAMP(7);  // wait for the prefetched batch
   // ---- stream back ----
-  // (lane -> LDS row j*64+lane holds chunk chunk_of(j) of board bl: the fill's mapping)
+  // (LDS row j, slot lane holds chunk j of board bl: the fill's mapping)
   char *const tile_cur = tile_of(idx);
   auto chunk_ptr = [&](int c) -> uint4 * {  // where chunk c of this lane's board lives
     if constexpr (FAST)
@@ -628,9 +619,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     // rolling compaction, where a reader cannot know a batch's position, clears them
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      if (wr && chunk_of(j) < CJ) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
-      if (FAST && rolling && wr && chunk_of(j) >= CJ && chunk_of(j) < CHT)
-        tile_store<NT>(chunk_ptr(chunk_of(j)), make_uint4(0u, 0u, 0u, 0u));
+      if (wr && j < CJ) tile_store<NT>(chunk_ptr(j), lds4[j * kWave + lane]);
+      if (FAST && rolling && wr && j >= CJ) tile_store<NT>(chunk_ptr(j), make_uint4(0u, 0u, 0u, 0u));
     }
   } else {
     // this move's record: all a step normally writes -- one dword per board, a contiguous line per
@@ -644,7 +634,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     STAMP(9);  // fixed store (journal record)
     // flag chunks a flood fill changed: every dirty board walks its own mask, all dirty
     // boards in parallel (per-lane chunk index), so the loop runs max-popcount times
-    uint32_t dd = (was_reset || !wr || half || (kAblate & 2)) ? 0u : dirty;
+    uint32_t dd = (was_reset || !wr || (kAblate & 2)) ? 0u : dirty;
     while (__ballot(dd != 0u)) {
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
@@ -656,11 +646,11 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && chunk_of(j) < CJ) tile_store<NT>(chunk_ptr(chunk_of(j)), lds4[j * kWave + lane]);
+        if (was_reset && j < CJ) tile_store<NT>(chunk_ptr(j), lds4[j * kWave + lane]);
     }
   }
   STAMP(11);  // reset lanes / compaction
-  if (inb && !flush && half == 0) {
+  if (inb && !flush) {
     if (status) {
       uint8_t st = (uint8_t)(result | (swapped << 5));
       if (illegal) st |= TWX_ST_ILLEGAL;
@@ -690,7 +680,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
     TicketBases tbase, int nstatic) {
-  step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+  step_body<N, SUB>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
                         rsteps, ticket, tbase, nstatic);
 }
 
@@ -706,7 +696,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TWX_SMALL
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
     TicketBases tbase, int nstatic) {
-  step_body<N, SUB, 64>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+  step_body<N, SUB>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
                         rsteps, ticket, tbase, nstatic);
 }
 

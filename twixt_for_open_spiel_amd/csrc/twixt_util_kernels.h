@@ -9,7 +9,7 @@
 // queries.  One thread per (board, chunk) or per board.
 // ---------------------------------------------------------------------------
 struct Dims {
-  int n, W, SW, CH, CHT;  // CH: state chunks (planes + scalars); CHT: + journal chunks
+  int n, W, SW, CH, CHT;  // CH: state chunks (planes + scalars); CHT: + the journal's chunk rows
   int ts;                 // tile_shift(CHT): boards per tile of the state array = 1 << ts
   long batch, bpad;
 };
@@ -36,7 +36,7 @@ __global__ void reset_kernel(uint4 *state, Dims d, const uint32_t *init, const i
     b = ids[j];
     if (b < 0 || b >= d.batch) return;
   }
-  uint4 v;  // init is in internal chunk order; scalars and journal chunks are zero
+  uint4 v;  // init is in internal chunk order; scalars and journal rows are zero
   v.x = init[4 * c + 0]; v.y = init[4 * c + 1]; v.z = init[4 * c + 2]; v.w = init[4 * c + 3];
   state[chunk_index(c, b, d.ts, d.CHT)] = v;
 }
