@@ -58,14 +58,13 @@ def step_kernel_name(n):
 def design_bytes(n):
     """Bytes this design moves per env step by construction, journal period
     P = journal_period(n): every launch reads the board's CH = 2W+1 chunks of 16 B (planes and
-    scalars) and the journal rows that hold records of the running period (16 B per board each:
-    row 0 from the second launch of a period on, row 1 from the sixth); P-1 launches in P write one
-    journal record (4 B: it carries the scalars), the P-th rewrites the CH chunks.  (Flag chunks a
-    multi-cell flood fill dirtied and auto-reset boards add a few bytes.)"""
+    scalars) and the journal records of the running period (4 B per board and record: launch j of a
+    period fetches j of them); P-1 launches in P write one journal record (4 B: it carries the
+    scalars), the P-th rewrites the CH chunks.  (Flag chunks a multi-cell flood fill dirtied,
+    auto-reset boards, and the 5 B of actions + status a step reports add a few bytes.)"""
     ch = 2 * ((n * n + 31) // 32) + 1
     p = journal_period(n)
-    rows = sum((j > 0) + (j > 4) for j in range(p))
-    return 16.0 * ch + 16.0 * rows / p + ((p - 1) * 4.0 + 16.0 * ch) / p
+    return 16.0 * ch + 4.0 * sum(range(p)) / p + ((p - 1) * 4.0 + 16.0 * ch) / p
 
 
 def host_cores():

@@ -125,8 +125,8 @@ def test_roofline_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
 
 def test_design_byte_model():
     import bench
-    # N=24, period 8: 37 chunks read + journal rows (row 0 in 7 launches, row 1 in 3); 7 records + one rewrite
-    assert bench.design_bytes(24) == 592 + 16 * (7 + 3) / 8 + (7 * 4 + 592) / 8 == 689.5
+    # N=24, period 8: 37 chunks read + the period's records so far (0..7 of 4 B); 7 records + one rewrite written
+    assert bench.design_bytes(24) == 592 + 4 * 28 / 8 + (7 * 4 + 592) / 8 == 683.5
     assert bench.design_bytes(8) == 2 * 80 and bench.journal_period(9) == 1        # no journal: read + write the board
     assert [bench.journal_period(n) for n in (10, 12, 13, 17, 18, 24)] == [2, 2, 4, 4, 8, 8]
     assert bench.step_kernel_name(24) == "step_pair_kernel<24>" and "small" in bench.step_kernel_name(12)

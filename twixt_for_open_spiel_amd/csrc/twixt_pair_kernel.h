@@ -108,8 +108,10 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     static_assert(c0 <= c1r, "the journal pairs belong to the last slice");
     pair_tile_load<c0, c1r>(nxt, voff, tile);
     if constexpr (c1 == NJ) {
-      if (!up || need_j1) pair_tile_load_chunk<NJ - 2>(nxt[NJ - 2], voff[(NJ - 2) / 8], tile);
-      if (!up && need_j2) pair_tile_load_chunk<NJ - 1>(nxt[NJ - 1], voff_tail, tile);
+      // (a journal row is four 128-byte lines, one per slot; lanes 8s..8s+7 of a half move slot s:
+      // only the slots that hold records of this period are fetched)
+      if (!up || (bl >> 3) < jpos) pair_tile_load_chunk<NJ - 2>(nxt[NJ - 2], voff[(NJ - 2) / 8], tile);
+      if (!up && (bl >> 3) < jpos - 4) pair_tile_load_chunk<NJ - 1>(nxt[NJ - 1], voff_tail, tile);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -162,7 +164,9 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       if (inb) a_ext = actions[row];
       asm volatile("" : "+v"(a_ext));  // the compiler's wait for this load belongs HERE, before the prefetch
     }
-    pair_tile_fill<0, NJ>(lds_lane, nxt);
+    pair_tile_fill<0, NJ - 2>(lds_lane, nxt);
+    if (!up || need_j1) pair_tile_fill<NJ - 2, NJ - 1>(lds_lane, nxt);  // scalars | journal row 0
+    if (need_j2) pair_tile_fill<NJ - 1, NJ>(lds_lane, nxt);             // journal row 1 (the upper lanes' slot is spare)
     wave_sync();
     const char *const tile_next = tile_of((idx_next < nbatch) ? idx_next : idx);
     __builtin_amdgcn_sched_barrier(0);

@@ -135,12 +135,16 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // records of older periods and are never looked at.  Listed-boards launches (jpos = 0) skip them.
   const bool rolling = (flags & kFlagRolling) != 0;
   const bool need_j1 = rolling || jpos_arg > 0, need_j2 = rolling || jpos_arg > 4;
+  // (a journal row of a tile is four lines, one per slot; this lane's 16 bytes of a row belong to slot
+  // jslot of row 0 and 4 + jslot of row 1: only the slots that hold records of the period are fetched)
+  const int jslot = (lane & ((1 << TS) - 1)) >> (TS - 2);
+  const bool load_j1 = rolling || jslot < jpos_arg, load_j2 = rolling || jslot < jpos_arg - 4;
   static_assert(twx::kJournalChunks == 2, "two journal rows");
   constexpr int NL = SUB ? CJ : NJ;  // chunks a listed-boards launch moves
   if constexpr (FAST) {
     tile_load<0, CJ, AG, TS>(nxt, voff, tile_of(idx));
-    if (need_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_of(idx));
-    if (need_j2) tile_load<CJ + 1, CHT, AG, TS>(nxt, voff, tile_of(idx));
+    if (load_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_of(idx));
+    if (load_j2) tile_load<CJ + 1, CHT, AG, TS>(nxt, voff, tile_of(idx));
     vm_wait_all();  // first batch: nothing to overlap with
   } else {
     long b0 = batch_board(idx);
@@ -215,8 +219,8 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       if constexpr (c1 == NJ) {
         static_assert(c0 <= CJ, "the journal rows belong to the last slice");
         tile_load<c0, CJ, AG, TS>(nxt, voff, tile_next);
-        if (need_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_next);
-        if (need_j2) tile_load<CJ + 1, CHT, AG, TS>(nxt, voff, tile_next);
+        if (load_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_next);
+        if (load_j2) tile_load<CJ + 1, CHT, AG, TS>(nxt, voff, tile_next);
       } else {
         tile_load<c0, c1, AG, TS>(nxt, voff, tile_next);
       }
