@@ -641,6 +641,11 @@ def test_capture_refused_on_a_default_handle(torch_mod):
         with torch.cuda.graph(g, stream=side):
             env.step_random(1, True, want_actions=False, want_status=False)
     torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(TwixtHipError, match="TWX_GRAPH_SAFE"):       # twx_status reads the journal up to a
+        with torch.cuda.graph(g2, stream=side):                        # position that is a launch argument
+            env.status()
+    torch.cuda.synchronize()
     env.step_random(1, True, want_actions=False, want_status=False)   # the handle is still usable
     torch.cuda.synchronize()
     env.close()
