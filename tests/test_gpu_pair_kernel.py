@@ -220,3 +220,55 @@ def test_external_actions_swaps_and_illegal_moves(torch_mod, pair, monkeypatch):
             assert np.array_equal(mc.cpu().numpy(), [bd.move_counter for bd in boards])
     assert any(bd.s.swapped for bd in boards)
     env.close()
+
+
+@pytest.mark.parametrize("n,batch", [(22, 330), (12, 450)])
+def test_whole_batch_and_listed_boards_interleaved(torch_mod, n, batch):
+    """Whole-batch steps (which journal), listed-boards steps, play-outs of a few boards and status
+    queries on one handle, in an order that leaves journal rows stale and boards reset in the middle
+    of a period: every board follows the oracle board that made the same moves."""
+    import oracle_binding as ob
+    torch = torch_mod
+    seed, first = 9, 77
+    rng = np.random.default_rng(n)
+    env = make_env(n, batch, first=first)
+    boards = [ob.Board(n) for _ in range(batch)]
+
+    def oracle_step(ids, auto_reset):
+        acts, stat = np.zeros(len(ids), dtype=np.int32), np.zeros(len(ids), dtype=np.uint8)
+        for j, b in enumerate(ids):
+            a, st, _ = boards[b].rollout(seed, first + int(b), 1, auto_reset)
+            acts[j], stat[j] = a[0], st[0]
+        return acts, stat
+
+    def oracle_planes():
+        ref = np.stack([bd.planes() for bd in boards])
+        ref[:, -2] = [bd.episode.value for bd in boards]   # (Board.planes leaves the episode word to the caller)
+        return ref
+
+    everyone = np.arange(batch)
+    for t in range(150):
+        kind = rng.integers(0, 10)
+        if kind < 6:                                  # whole batch, auto-reset: appends a journal record
+            a, st = env.step_random(seed, True)
+            ra, rs = oracle_step(everyone, True)
+            assert np.array_equal(a.cpu().numpy(), ra) and np.array_equal(st.cpu().numpy(), rs), "whole-batch step %d" % t
+        elif kind < 8:                                # a few listed boards: flushes the journal first
+            ids = np.sort(rng.choice(batch, size=int(rng.integers(1, 90)), replace=False)).astype(np.int32)
+            a, st = env.step_random(seed, True, ids=torch.from_numpy(ids))
+            ra, rs = oracle_step(ids, True)
+            assert np.array_equal(a.cpu().numpy(), ra) and np.array_equal(st.cpu().numpy(), rs), "listed step %d" % t
+        elif kind == 8:                               # status in the middle of a period: no flush
+            res, mc, cp = env.status()
+            assert np.array_equal(res.cpu().numpy(), [bd.result for bd in boards]), "status at %d" % t
+            assert np.array_equal(mc.cpu().numpy(), [bd.move_counter for bd in boards])
+        else:                                         # play three boards out (a compaction of listed boards)
+            ids = np.sort(rng.choice(batch, size=3, replace=False)).astype(np.int32)
+            st = env.random_rollout(seed, ids=torch.from_numpy(ids)).cpu().numpy()
+            for j, b in enumerate(ids):
+                boards[b].rollout(seed, first + int(b), n * n, False)
+                assert (st[j] & 3) == boards[b].result and boards[b].result != 0
+        if t % 25 == 24:
+            compare_planes(env, oracle_planes(), what="after %d calls" % (t + 1))
+    compare_planes(env, oracle_planes(), what="final")
+    env.close()
