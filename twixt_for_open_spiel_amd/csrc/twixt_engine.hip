@@ -424,6 +424,10 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     int per_cu = step_tables().occ[n]();
     if (per_cu < 1) per_cu = 4;
     if (per_cu > 16) per_cu = 16;
+    // N = 12 (13 chunk rows) fits three waves per SIMD by registers and LDS, and runs 22 % SLOWER with
+    // them than with two (0.0762 vs 0.0623 ms per 2^20-board step; N = 10, 11 gain 8 % from the third
+    // wave, N >= 13 do not fit it): tools/sweep_waves.sh, profiles/r02_waves_per_cu_sweep.txt
+    if (e->d.CHT >= 13 && per_cu > 8) per_cu = 8;
     e->waves = (cus > 0 ? cus : 256) * env_int("TWX_WAVES_PER_CU", per_cu, 1, 32);
     const int pocc = step_tables().pocc[n]();
     e->pair = pocc > 0 && env_int("TWX_PAIR", 1, 0, 1) != 0;

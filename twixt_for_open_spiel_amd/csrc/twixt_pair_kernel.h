@@ -267,9 +267,12 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     const bool open = (result == 0u);
 
     // ---- legal mask of the player to move (tw.h:86-90), this lane's half of the
-    //      word groups; counts of both colours for the draw test (tb.cc:202-206) ----
+    //      word groups, and the opponent's free-cell count for the draw test (tb.cc:202-206).  The
+    //      opponent cannot be out of cells while fewer pegs are on the board than its region has
+    //      cells: the count is taken only when some board of the wave is that full (wave-uniform) ----
     uint32_t m[WH];
-    int pr = 0, pb = 0, pm = 0;
+    const bool count_opp = __ballot(counter + 1u >= (uint32_t)(N * (N - 2))) != 0ull;
+    int po = 0, pm = 0;
 #pragma unroll
     for (int ii = 0; ii < WH; ii++) {
       const uint2 rb = *reinterpret_cast<const uint2 *>(meh + ii * GS);
@@ -280,18 +283,14 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       const uint32_t r0l = G::tab.region[0][ii], r0u = has_u ? G::tab.region[0][has_u ? WH + ii : 0] : 0u;
       const uint32_t r1l = G::tab.region[1][ii], r1u = has_u ? G::tab.region[1][has_u ? WH + ii : 0] : 0u;
       const uint32_t reg_r = r0l ^ ((r0l ^ r0u) & hm), reg_b = r1l ^ ((r1l ^ r1u) & hm);
-      const uint32_t mr = reg_r & ~occ;
-      uint32_t mb = reg_b & ~occ;
-      pr += __popc(mr);
-      pb += __popc(mb);
-      if (counter == 1u) mb = reg_b & ~rb.y;  // red's first peg stays legal for blue: the swap
-      m[ii] = player ? mb : mr;
+      // (move 1, blue to move: red's first peg stays legal for blue -- the swap)
+      m[ii] = (player ? reg_b : reg_r) & ~((counter == 1u) ? rb.y : occ);
       pm += __popc(m[ii]);
+      if (count_opp) po += __popc((player ? reg_r : reg_b) & ~occ);
     }
-    const PairVal pc = pair_swap((uint32_t)pr | ((uint32_t)pb << 10) | ((uint32_t)pm << 20));
-    const int cnt_r = (int)((pc.lo & 1023u) + (pc.hi & 1023u)), cnt_b = (int)(((pc.lo >> 10) & 1023u) + ((pc.hi >> 10) & 1023u));
-    const int cnt_lo = (int)(pc.lo >> 20), cnt = cnt_lo + (int)(pc.hi >> 20);
-    const int cnt_opp = player ? cnt_r : cnt_b;
+    const PairVal pc = pair_swap((uint32_t)pm | ((uint32_t)po << 10));
+    const int cnt_lo = (int)(pc.lo & 1023u), cnt = cnt_lo + (int)(pc.hi & 1023u);
+    const int cnt_opp = count_opp ? (int)((pc.lo >> 10) + (pc.hi >> 10)) : (1 << 20);  // "plenty": no draw
 
     // ---- choose / validate the action ----
     int a = -1;

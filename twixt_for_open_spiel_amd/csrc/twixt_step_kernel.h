@@ -328,25 +328,30 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   const int player = (int)(counter & 1u);
   const bool open = (result == 0u);
 
-  // ---- legal mask of the player to move (tw.h:86-90) and the
-  //      opponent's free-cell count (for the draw test of tb.cc:202-206) ----
+  // ---- legal mask of the player to move (tw.h:86-90) and the opponent's free-cell
+  //      count for the draw test of tb.cc:202-206.  The opponent cannot be out of cells while fewer
+  //      pegs are on the board than its region has cells, so the count is taken only when some board
+  //      of the wave is that full (wave-uniform; never at N >= 9 in random play). ----
   uint32_t m[W];
-  int cnt_r = 0, cnt_b = 0;
+  const bool count_opp = __ballot(counter + 1u >= (uint32_t)(N * (N - 2))) != 0ull;
+  int cnt_opp = 1 << 20;  // "plenty": the draw test below cannot fire
+  if (count_opp) {
+    cnt_opp = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      const uint2 rb = *reinterpret_cast<const uint2 *>(me + i * GS);
+      cnt_opp += __popc((player ? G::tab.region[0][i] : G::tab.region[1][i]) & ~(rb.x | rb.y));
+    }
+  }
+  int cnt = 0;
 #pragma unroll
   for (int i = 0; i < W; i++) {
     const uint2 rb = *reinterpret_cast<const uint2 *>(me + i * GS);
-    const uint32_t occ = rb.x | rb.y;
-    uint32_t mr = G::tab.region[0][i] & ~occ;
-    uint32_t mb = G::tab.region[1][i] & ~occ;
-    cnt_r += __popc(mr);
-    cnt_b += __popc(mb);
-    if (counter == 1u) mb = G::tab.region[1][i] & ~rb.y;  // red's first peg stays legal for blue: the swap
-    m[i] = player ? mb : mr;
+    // (move 1, blue to move: red's first peg stays legal for blue -- the swap)
+    const uint32_t occ = (counter == 1u) ? rb.y : (rb.x | rb.y);
+    m[i] = (player ? G::tab.region[1][i] : G::tab.region[0][i]) & ~occ;
+    cnt += __popc(m[i]);
   }
-  const int cnt_opp = player ? cnt_r : cnt_b;
-  int cnt = 0;
-#pragma unroll
-  for (int i = 0; i < W; i++) cnt += __popc(m[i]);
 
   STAMP(3);  // legal mask + counts
   // ---- choose / validate the action ----
