@@ -85,7 +85,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(n, seed, budget_s=12.0):
+def cpu_baseline(n, seed, budget_s=18.0):
     """Times the CPU oracle (the scalar port of the reference's algorithm) on all
     host cores with the same policy and workload shape.  Checker code used as a
     *reported baseline only*; its budget does not depend on --steps."""
