@@ -294,6 +294,16 @@ def spawn_ranks(args):
     return rc
 
 
+def claim_stdout():
+    """Keeps the real stdout for the ONE JSON line and points fd 1 at stderr for everything else:
+    libraries print there behind Python's back (Gloo's "Rank 0 is connected to 1 peer ranks" banner is
+    a C++ write to stdout), and the driver reads stdout as the bench line."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
@@ -308,6 +318,7 @@ def main(argv=None):
         local = int(os.environ.get("LOCAL_RANK", str(rank)))
         if world != args.gpus:
             raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    json_out = claim_stdout()  # (a rank process; the parent that only starts the ranks prints nothing)
 
     dist = None
     if world > 1:
@@ -454,7 +465,8 @@ def main(argv=None):
             out["small_batch"] = small_batch_latency(dev, args.seed)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(n, args.seed)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if env is not None:
         env.close()
     if dist is not None:

@@ -31,8 +31,10 @@ def _run_bench(extra, env=None, timeout=240):
 
 
 def _json_line(out):
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out
+    """stdout is the bench line and nothing else: bench.py keeps library chatter (Gloo's connection
+    banner is written to stdout by C++) on stderr."""
+    lines = out.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out
     return json.loads(lines[0])
 
 
@@ -65,7 +67,7 @@ def test_bench_under_a_launcher_environment():
     outs = [p.communicate(timeout=240) for p in procs]
     assert [p.returncode for p in procs] == [0, 0], outs
     js = _json_line(outs[0][0])
-    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
+    assert outs[1][0] == ""                                       # only rank 0 prints, and only the line
     assert js["n_gpus"] == 2 and js["config"]["first_board_ids"] == [0, 128]
 
 
