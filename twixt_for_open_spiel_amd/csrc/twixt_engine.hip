@@ -66,14 +66,14 @@ int fail(int code, const std::string &msg) {
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
-                       const int32_t *ids, long nsub, int rsteps, uint32_t *ticket, TicketBases ticket_base,
+                       const int32_t *ids, long nsub, int rsteps, int rpw, uint32_t *ticket, TicketBases ticket_base,
                        int nstatic, hipStream_t s) {
-  const long nbatch = ids ? (nsub + kWave - 1) / kWave : bpad / kWave;
+  const long nbatch = ids ? (nsub + rpw - 1) / rpw : bpad / kWave;  // rpw: rows of the list per wave
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
   const size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // the wave's 64 boards: 39 KiB at N=24
 #define TWX_LAUNCH(K)                                                                                      \
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
-                     actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, ticket, ticket_base, nstatic)
+                     actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, rpw, ticket, ticket_base, nstatic)
   if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT) {
     if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
   } else {
@@ -127,7 +127,7 @@ typedef hipError_t (*pair_fn)(uint4 *, long, long, const int32_t *, int32_t *, u
 
 typedef int (*occ_fn)();
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, const int32_t *, long, int, uint32_t *, TicketBases, int, hipStream_t);
+                              int, int, int, const int32_t *, long, int, int, uint32_t *, TicketBases, int, hipStream_t);
 
 template <int N>
 struct StepTable {
@@ -179,6 +179,7 @@ struct twx_env {
   int init_off;    // word offset of the initial-position chunks inside `tables`
   bool pair;       // whole-batch launches go to step_pair_kernel (two lanes per board; big boards)
   int waves_pair;  // its persistent grid
+  int cus;         // compute units of the device
   // dynamic batch order (TWX_DYNAMIC): device ticket counters (never reset) and the values
   // they will have when the next launch starts
   bool dynamic;
@@ -271,7 +272,12 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   {
     // whole-batch launches of the big boards: the two-lanes-per-board kernel
     const bool use_pair = e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling);
-    const int bpw = use_pair ? 32 : kWave, waves = use_pair ? e->waves_pair : e->waves;  // boards per wave
+    int bpw = use_pair ? 32 : kWave;  // boards per wave
+    const int waves = use_pair ? e->waves_pair : e->waves;
+    // a short list of boards is spread over many waves (rows per wave: a power of two, at least 4,
+    // while that still fills four waves per CU): see step_body
+    if (ids)
+      while (bpw > 4 && (nsub + bpw - 1) / bpw < 4L * e->cus) bpw >>= 1;
     // dynamic tail: the groups need equal numbers of waves, and there must be batches beyond
     // the first round; by default the last eighth of the rounds (at least two) is dynamic
     const long nbatch = ids ? (nsub + bpw - 1) / bpw : e->d.bpad / bpw;
@@ -296,7 +302,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
                                          (int)nstatic, s));
     else
       HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
-                               (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, e->ticket,
+                               (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, bpw, e->ticket,
                                e->ticket_base, (int)nstatic, s));
     if (dyn) {
       // group g: its dynamic batches (idx >= nstatic * grid, idx % groups == g) + two draws per
@@ -395,6 +401,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   int cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
   twx_env *e = new twx_env();
+  e->cus = cus > 0 ? cus : 256;
   e->d.n = n;
   e->d.W = twx::plane_words(n);
   e->d.SW = twx::state_words(n);

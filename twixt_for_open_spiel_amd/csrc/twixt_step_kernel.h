@@ -31,7 +31,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
                                                      uint8_t *__restrict__ status, uint32_t seed,
                                                      uint32_t first_id, int flags, int jpos_arg,
                                                      const int32_t *__restrict__ ids_arg, long nsub,
-                                                     int rsteps, uint32_t *__restrict__ ticket,
+                                                     int rsteps, int rpw, uint32_t *__restrict__ ticket,
                                                      TicketBases tbase, int nstatic) {
   using G = twx::Geo<N>;
   const int32_t *const ids = SUB ? ids_arg : nullptr;  // compile-time null in the whole-batch kernel
@@ -65,7 +65,12 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // Rows: the boards this launch works on.  Whole batch: row j is board j (the allocation
   // is padded to a multiple of 64, padded boards are real storage).  Subset (`ids`): row j
   // is board ids[j]; lanes past nsub load board 0 and store nothing.
-  const long nbatch = ids ? (nsub + BPW - 1) / BPW : bpad / BPW;
+  // A listed-boards launch gives a wave only RPW rows (a power of two, the host's choice): a short
+  // list spread over many waves finishes sooner than a few full ones, because the flood fills of a
+  // wave's boards run one after the other (2,048 play-outs at N=12: 0.44 ms with 64 boards per
+  // wave, 0.28 ms with 8).  Lanes RPW..63 are padding lanes then.
+  const int RPW = SUB ? rpw : BPW;
+  const long nbatch = ids ? (nsub + RPW - 1) / RPW : bpad / BPW;
 
   // Persistent wave: walks batches idx = blockIdx.x, +gridDim.x, ...  While batch k is
   // processed out of LDS, batch k+1 is already streaming into VGPRs (CHT x 16 B per
@@ -73,10 +78,10 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // kFlagReverse walks the batches backwards: the boards a launch touched last are the
   // ones the next launch touches first (Infinity Cache reuse).
   auto batch_row = [&](long idx) -> long {
-    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * BPW + bl;
+    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * RPW + bl;
   };
   // (an id outside [0, batch) makes its row a padding lane: nothing is stored, status untouched)
-  auto row_board = [&](long j) -> long { return ids ? (j < nsub ? (long)ids[j] : -1L) : j; };
+  auto row_board = [&](long j) -> long { return ids ? ((bl < RPW && j < nsub) ? (long)ids[j] : -1L) : j; };
   auto batch_board = [&](long idx) -> long { return row_board(batch_row(idx)); };
   STAMP_DECL;
   u32x4 nxt[NJ];
@@ -687,10 +692,10 @@ template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel64(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, int rpw, uint32_t *__restrict__ ticket,
     TicketBases tbase, int nstatic) {
   step_body<N, SUB>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                        rsteps, ticket, tbase, nstatic);
+                    rsteps, rpw, ticket, tbase, nstatic);
 }
 
 
@@ -703,10 +708,10 @@ template <int N, bool SUB>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TWX_SMALL_MIN_WAVES, 8))) void step_kernel64_small(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, uint32_t *__restrict__ ticket,
+    int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, int rpw, uint32_t *__restrict__ ticket,
     TicketBases tbase, int nstatic) {
   step_body<N, SUB>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                        rsteps, ticket, tbase, nstatic);
+                    rsteps, rpw, ticket, tbase, nstatic);
 }
 
 #endif  // TWIXT_STEP_KERNEL_H_
