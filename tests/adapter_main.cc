@@ -2,6 +2,7 @@
 // API model in tests/spiel_stub.  Re-expresses the reference's twixt_test.cc (25-199) and
 // replays an action list given on the command line, printing every state so that
 // tests/test_adapter.py can compare with the playthrough fixture.  Needs a GPU to run.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -147,8 +148,29 @@ static void Replay(int argc, char **argv) {
   }
 }
 
+// "latency": what one State call costs through the adapter (a random N=8 game per repetition)
+static void Latency() {
+  auto game = LoadGame("twixt");
+  std::mt19937 rng(3);
+  long calls = 0, moves = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int g = 0; g < 200; g++) {
+    auto state = game->NewInitialState();
+    while (!state->IsTerminal()) {
+      auto la = state->LegalActions();
+      state->ApplyAction(la[rng() % la.size()]);
+      calls += 2;
+      moves++;
+    }
+  }
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("LATENCY %.1f us per State call (LegalActions / ApplyAction alternating, %ld moves of 200 random games)\n",
+              us / calls, moves);
+}
+
 int main(int argc, char **argv) {
   SetErrorHandler(Throwing);
+  if (argc > 1 && !std::strcmp(argv[1], "latency")) { Latency(); return 0; }
   ParameterTest();
   SwapTest();
   LegalActionsTest();

@@ -3,7 +3,9 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 
 #include "open_spiel/spiel_utils.h"
@@ -74,23 +76,24 @@ DeviceBoards::DeviceBoards(int board_size, int capacity, int device)
   mask_words_ = twx_mask_words(board_size);
   free_.reserve(capacity);
   for (int i = capacity - 1; i >= 0; --i) free_.push_back(i);
-  Hip(hipMalloc(&d_ids_, 4));
-  Hip(hipMalloc(&d_ids2_, 4));
-  Hip(hipMalloc(&d_action_, 4));
-  Hip(hipMalloc(&d_status_, 4));
-  Hip(hipMalloc(&d_mask_, 4 * mask_words_ + 4));
-  Hip(hipMalloc(&d_obs_, sizeof(float) * kNumPlanes * n_ * (n_ - 2)));
-  Hip(hipMalloc(&d_cells_, 4 * n_ * n_));
+  auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+  off_mask_ = up(sizeof(Scratch));
+  off_obs_ = off_mask_ + up(4 * (size_t)mask_words_);
+  off_cells_ = off_obs_ + up(sizeof(float) * kNumPlanes * n_ * (n_ - 2));
+  const size_t bytes = off_cells_ + up(4 * (size_t)n_ * n_);
+  Hip(hipHostMalloc(&pin_, bytes, hipHostMallocMapped));
+  void *d = nullptr;
+  Hip(hipHostGetDevicePointer(&d, pin_, 0));
+  dev_ = static_cast<char *>(d);
 }
 
 DeviceBoards::~DeviceBoards() {
   OnDevice guard(device_);
-  for (void *p : {d_ids_, d_ids2_, d_action_, d_status_, d_mask_, d_obs_, d_cells_})
-    if (p) (void)hipFree(p);
   twx_destroy(env_);
+  if (pin_) (void)hipHostFree(pin_);
 }
 
-void DeviceBoards::PutId(void *dst, int32_t slot) { Hip(hipMemcpy(dst, &slot, 4, hipMemcpyHostToDevice)); }
+void DeviceBoards::Finish() { Hip(hipStreamSynchronize(nullptr)); }
 
 int32_t DeviceBoards::Acquire() {
   std::lock_guard<std::mutex> lock(mu_);
@@ -100,8 +103,9 @@ int32_t DeviceBoards::Acquire() {
                     std::to_string(capacity_) + ")");
   const int32_t slot = free_.back();
   free_.pop_back();
-  PutId(d_ids_, slot);
-  Twx(twx_reset_boards(env_, static_cast<const int32_t *>(d_ids_), 1, nullptr));  // Board::Board
+  scratch()->ids[0] = slot;
+  Twx(twx_reset_boards(env_, dev_at<int32_t>(offsetof(Scratch, ids)), 1, nullptr));  // Board::Board
+  Finish();  // (the id is read by the launch: the block must not change under it)
   return slot;
 }
 
@@ -113,57 +117,57 @@ void DeviceBoards::Release(int32_t slot) {
 void DeviceBoards::Copy(int32_t dst, int32_t src) {
   std::lock_guard<std::mutex> lock(mu_);
   OnDevice guard(device_);
-  PutId(d_ids_, dst);
-  PutId(d_ids2_, src);
-  Twx(twx_copy_boards(env_, static_cast<const int32_t *>(d_ids_), env_, static_cast<const int32_t *>(d_ids2_), 1,
-                      nullptr));
+  scratch()->ids[0] = dst;
+  scratch()->ids[1] = src;
+  const int32_t *ids = dev_at<int32_t>(offsetof(Scratch, ids));
+  Twx(twx_copy_boards(env_, ids, env_, ids + 1, 1, nullptr));
+  Finish();
 }
 
 uint8_t DeviceBoards::Step(int32_t slot, Action action) {
   std::lock_guard<std::mutex> lock(mu_);
   OnDevice guard(device_);
-  PutId(d_ids_, slot);
+  scratch()->ids[0] = slot;
   // an action outside int32 can never be legal: any out-of-range value reports "illegal"
-  const int32_t a = (action < 0 || action > 0x7fffffff) ? -1 : static_cast<int32_t>(action);
-  Hip(hipMemcpy(d_action_, &a, 4, hipMemcpyHostToDevice));
-  Twx(twx_step_boards(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<const int32_t *>(d_action_),
-                      static_cast<uint8_t *>(d_status_), nullptr));
-  uint8_t st = 0;
-  Hip(hipMemcpy(&st, d_status_, 1, hipMemcpyDeviceToHost));
-  return st;
+  scratch()->action = (action < 0 || action > 0x7fffffff) ? -1 : static_cast<int32_t>(action);
+  Twx(twx_step_boards(env_, dev_at<int32_t>(offsetof(Scratch, ids)), 1, dev_at<int32_t>(offsetof(Scratch, action)),
+                      dev_at<uint8_t>(offsetof(Scratch, status)), nullptr));
+  Finish();
+  return scratch()->status[0];
 }
 
 std::vector<Action> DeviceBoards::LegalActions(int32_t slot) {
   std::lock_guard<std::mutex> lock(mu_);
   OnDevice guard(device_);
-  PutId(d_ids_, slot);
-  Twx(twx_legal_mask_boards(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<uint32_t *>(d_mask_),
-                            nullptr, nullptr));
-  std::vector<uint32_t> mask(mask_words_);
-  Hip(hipMemcpy(mask.data(), d_mask_, 4 * mask_words_, hipMemcpyDeviceToHost));
+  scratch()->ids[0] = slot;
+  Twx(twx_legal_mask_boards(env_, dev_at<int32_t>(offsetof(Scratch, ids)), 1, dev_at<uint32_t>(off_mask_), nullptr,
+                            nullptr));
+  Finish();
+  const uint32_t *mask = host_at<uint32_t>(off_mask_);
   std::vector<Action> out;
-  for (int a = 0; a < n_ * n_; ++a)  // ascending, like the reference's lists (twixtboard.cc:260-275)
-    if ((mask[a >> 5] >> (a & 31)) & 1u) out.push_back(a);
+  for (int w = 0; w < mask_words_; ++w)  // ascending, like the reference's lists (twixtboard.cc:260-275)
+    for (uint32_t m = mask[w]; m; m &= m - 1) out.push_back(32 * w + __builtin_ctz(m));
   return out;
 }
 
 void DeviceBoards::Observation(int32_t slot, float *out) {
   std::lock_guard<std::mutex> lock(mu_);
   OnDevice guard(device_);
-  PutId(d_ids_, slot);
-  Twx(twx_observation_boards(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<float *>(d_obs_), nullptr));
-  Hip(hipMemcpy(out, d_obs_, sizeof(float) * kNumPlanes * n_ * (n_ - 2), hipMemcpyDeviceToHost));
+  scratch()->ids[0] = slot;
+  Twx(twx_observation_boards(env_, dev_at<int32_t>(offsetof(Scratch, ids)), 1, dev_at<float>(off_obs_), nullptr));
+  Finish();
+  std::memcpy(out, host_at<float>(off_obs_), sizeof(float) * kNumPlanes * n_ * (n_ - 2));
 }
 
 std::string DeviceBoards::ToString(int32_t slot, bool ansi, bool swapped, int result) {
   std::lock_guard<std::mutex> lock(mu_);
   OnDevice guard(device_);
-  PutId(d_ids_, slot);
-  Twx(twx_export_cells(env_, static_cast<const int32_t *>(d_ids_), 1, static_cast<uint8_t *>(d_cells_), nullptr));
-  std::vector<uint8_t> cells(4 * n_ * n_);
-  Hip(hipMemcpy(cells.data(), d_cells_, cells.size(), hipMemcpyDeviceToHost));
-  std::string s(twx_cells_to_string(cells.data(), n_, ansi, swapped, result, nullptr, 0) + 1, '\0');
-  twx_cells_to_string(cells.data(), n_, ansi, swapped, result, &s[0], static_cast<int>(s.size()));
+  scratch()->ids[0] = slot;
+  Twx(twx_export_cells(env_, dev_at<int32_t>(offsetof(Scratch, ids)), 1, dev_at<uint8_t>(off_cells_), nullptr));
+  Finish();
+  const uint8_t *cells = host_at<uint8_t>(off_cells_);
+  std::string s(twx_cells_to_string(cells, n_, ansi, swapped, result, nullptr, 0) + 1, '\0');
+  twx_cells_to_string(cells, n_, ansi, swapped, result, &s[0], static_cast<int>(s.size()));
   s.pop_back();
   return s;
 }

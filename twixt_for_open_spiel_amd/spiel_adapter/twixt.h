@@ -55,9 +55,21 @@ class DeviceBoards {
   std::mutex mu_;
   twx_env *env_ = nullptr;
   std::vector<int32_t> free_;
-  void *d_ids_ = nullptr, *d_ids2_ = nullptr, *d_action_ = nullptr, *d_status_ = nullptr, *d_mask_ = nullptr,
-       *d_obs_ = nullptr, *d_cells_ = nullptr;
-  void PutId(void *dst, int32_t slot);
+  // One block of pinned host memory that the device reads and writes in place (hipHostMallocMapped):
+  // board ids and the action go in, status / legal mask / tensor / cells come out, so a State call is
+  // one launch and one stream synchronisation with no staging copies.
+  struct Scratch {
+    int32_t ids[2];
+    int32_t action;
+    uint8_t status[4];
+  };
+  void *pin_ = nullptr;            // the block as the host sees it
+  char *dev_ = nullptr;            // ... and as the device does
+  size_t off_mask_ = 0, off_obs_ = 0, off_cells_ = 0;
+  Scratch *scratch() { return static_cast<Scratch *>(pin_); }
+  template <typename T> T *host_at(size_t off) { return reinterpret_cast<T *>(static_cast<char *>(pin_) + off); }
+  template <typename T> T *dev_at(size_t off) { return reinterpret_cast<T *>(dev_ + off); }
+  void Finish();                   // waits for the launch (default stream) that fills the block
 };
 
 class TwixTState : public State {
