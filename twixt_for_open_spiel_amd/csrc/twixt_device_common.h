@@ -209,9 +209,21 @@ constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush 
 // dynamic batch order: one ticket counter per group of waves (blockIdx.x % kTicketGroups),
 // counters kTicketStride words apart; the bases travel as a kernel argument
 #ifndef TWX_TICKET_GROUPS
-#define TWX_TICKET_GROUPS 4  // measured: 1 and 2 contend on the counter, 4..16 are within 1 %
+#define TWX_TICKET_GROUPS 8  // one per XCD label (reversed_batch below); 1 and 2 contend on the counter
 #endif
 constexpr int kTicketGroups = TWX_TICKET_GROUPS, kTicketStride = 64;
+// Batch a wave works on when the launch walks the batches backwards (kFlagReverse).  Workgroups are
+// dealt to the eight XCDs round-robin (blocks b and b + 8 share one) and the persistent grids are
+// multiples of 8, so in a forward launch batch t is worked on by the XCD with label t % 8, statically
+// (t = b + round * grid) and by ticket (eight ticket groups, group = b % 8).  The backward walk keeps
+// that: blocks of 8 batches are reversed, the order inside a block stays (a ragged last block stays
+// last).  What a launch leaves in an XCD's L2 -- the L2s are private to their XCDs -- is then asked
+// for again on the same XCD by the next launch: +1.2 % at N=24, +7..8 % at N=19..21, every size gains
+// (profiles/r02_xcd_order_ab.txt).
+__device__ __forceinline__ long reversed_batch(long i, long nbatch) {
+  const long q = nbatch & ~7L;
+  return i < q ? (((q - 1 - i) & ~7L) | (i & 7L)) : i;
+}
 struct TicketBases { uint32_t b[kTicketGroups]; };
 
 #endif  // TWIXT_DEVICE_COMMON_H_

@@ -286,7 +286,8 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     // launch draws about 4 * grid / kTicketGroups tickets per counter in (nbatch / grid) batch
     // times of ~10 us, so the tail is dynamic only while grid^2 <= 300 * nbatch.  Measured at
     // B=2^20: +5..7 % for N >= 12 (2,048 waves and fewer), -12 % / -29 % at N=8 / N=5 (3,072 /
-    // 4,096 waves), which this rule keeps static.
+    // 4,096 waves), which this rule keeps static.  (With eight ticket groups instead of four the
+    // bound could be twice as high; measured: +2 % at N=6, -5 % at N=9, nothing elsewhere: kept.)
     const bool dyn = e->dynamic && grid % kTicketGroups == 0 && nbatch > grid && grid * grid <= 300 * nbatch;
     const long rounds = nbatch / grid;  // whole rounds
     // (the pair kernel's waves hold half as many boards, so one long flood fill weighs more: the

@@ -81,7 +81,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   };
   // batch i -> its 32 boards = one tile of the state array (tile_shift 5: CHT rows of 512 B)
   static_assert(tile_shift(CHT) == 5, "step_pair_kernel works on 32-board tiles");
-  auto batch_of = [&](long i) -> long { return (flags & kFlagReverse) ? (nbatch - 1 - i) : i; };
+  auto batch_of = [&](long i) -> long { return (flags & kFlagReverse) ? reversed_batch(i, nbatch) : i; };
   auto tile_of = [&](long i) -> char * { return reinterpret_cast<char *>(state) + batch_of(i) * (long)(CHT * 512); };
 
   // a journal row (slots 0..3: chunk row CJ, the upper lane's half of pair W; slots 4..7: the odd

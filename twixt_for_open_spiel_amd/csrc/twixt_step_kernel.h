@@ -78,7 +78,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // kFlagReverse walks the batches backwards: the boards a launch touched last are the
   // ones the next launch touches first (Infinity Cache reuse).
   auto batch_row = [&](long idx) -> long {
-    return ((flags & kFlagReverse) ? (nbatch - 1 - idx) : idx) * RPW + bl;
+    return ((flags & kFlagReverse) ? reversed_batch(idx, nbatch) : idx) * RPW + bl;
   };
   // (an id outside [0, batch) makes its row a padding lane: nothing is stored, status untouched)
   auto row_board = [&](long j) -> long { return ids ? ((bl < RPW && j < nsub) ? (long)ids[j] : -1L) : j; };
@@ -131,7 +131,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   const uint32_t lds_lane = (uint32_t)(uintptr_t)((lds_u32 *)lds) + (uint32_t)lane * 16u;
   auto tile_of = [&](long i) -> char * {
-    const long t = (flags & kFlagReverse) ? (nbatch - 1 - i) : i;
+    const long t = (flags & kFlagReverse) ? reversed_batch(i, nbatch) : i;
     return reinterpret_cast<char *>(state) + t * (long)(CHT * 1024);
   };
   // A journal row (chunk row CJ: slots 0..3, CJ + 1: slots 4..7) is read only when a slot in it
@@ -176,7 +176,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   bool compact = compact_all;
   if (rolling) {
     const int period = (flags >> 8) & 15;
-    const long tb = (flags & kFlagReverse) ? (nbatch - 1 - idx) : idx;
+    const long tb = (flags & kFlagReverse) ? reversed_batch(idx, nbatch) : idx;
     // (+ tb / stride: a wave's successive batches tb, tb+stride, ... get different
     // positions, so every wave compacts its share in every launch; `stride` is a per-handle
     // constant, bits 12..27 of flags, so a batch's position is the same in every launch)
