@@ -217,9 +217,9 @@ constexpr int kTicketGroups = TWX_TICKET_GROUPS, kTicketStride = 64;
 // multiples of 8, so in a forward launch batch t is worked on by the XCD with label t % 8, statically
 // (t = b + round * grid) and by ticket (eight ticket groups, group = b % 8).  The backward walk keeps
 // that: blocks of 8 batches are reversed, the order inside a block stays (a ragged last block stays
-// last).  What a launch leaves in an XCD's L2 -- the L2s are private to their XCDs -- is then asked
-// for again on the same XCD by the next launch: +1.2 % at N=24, +7..8 % at N=19..21, every size gains
-// (profiles/r02_xcd_order_ab.txt).
+// last).  A board's lines are then asked for by the same XCD in every launch: +1.2 % at N=24, +7..8 %
+// at N=19..21, every size gains (profiles/r02_xcd_order_ab.txt; a memory-side effect: the L2 hit
+// counts do not change).
 __device__ __forceinline__ long reversed_batch(long i, long nbatch) {
   const long q = nbatch & ~7L;
   return i < q ? (((q - 1 - i) & ~7L) | (i & 7L)) : i;
