@@ -13,7 +13,6 @@
 class Device {
  public:
   Device(int n, int leaves, int games, int threads) : n_(n), L_(leaves), roots_(games), threads_(threads) {
-    (void)L_;
     const char *t = std::getenv("MCTS_CPU_THREADS");  // leaves are independent: all host cores by default
     eval_threads_ = t ? std::atoi(t) : 0;
   }
@@ -32,10 +31,12 @@ class Device {
         std::exit(1);
       }
   }
-  std::vector<Leaf> Evaluate(const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of,
-                             uint32_t seed) {
-    const int k = (int)paths.size();
-    std::vector<Leaf> out(k);
+  int LaneLeaves() const { return L_ >= 2 ? L_ / 2 : L_; }
+  // the driver's two-lane interface: here the lane is evaluated on the spot and handed over by Wait()
+  void Launch(int lane, const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of, uint32_t seed) {
+    const int k = (int)paths.size(), base = lane * LaneLeaves();
+    std::vector<Leaf> &out = lane_out_[lane];
+    out.assign(k, Leaf());
     Timer tm(3);
     const int nt = eval_threads_ > 0 ? eval_threads_ : HostCoresForEval();
     if (std::getenv("MCTS_CPU_DEBUG")) std::fprintf(stderr, "eval threads %d\n", nt);
@@ -51,12 +52,12 @@ class Device {
       Describe(s, &out[i]);
       if (s.result == ORC_OPEN) {
         uint32_t episode = 0;
-        orc_rollout(&s, seed, (uint32_t)i, &episode, n_ * n_ - 3, 0, nullptr, nullptr);
+        orc_rollout(&s, seed, (uint32_t)(base + i), &episode, n_ * n_ - 3, 0, nullptr, nullptr);  // board id = leaf slot
         out[i].final_result = s.result;
       }
     }
-    return out;
   }
+  std::vector<Leaf> Wait(int lane) { return std::move(lane_out_[lane]); }
 
  private:
   static int HostCoresForEval() {
@@ -84,4 +85,5 @@ class Device {
   int n_, L_;
   std::vector<orc_state> roots_;
   int threads_, eval_threads_ = 0;
+  std::vector<Leaf> lane_out_[2];
 };

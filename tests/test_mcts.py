@@ -31,13 +31,13 @@ class OracleEvaluator:
         b = self._board()
         return b.result, b.current_player(), b.legal_actions()
 
-    def evaluate(self, paths, seed):
+    def evaluate(self, paths, seed, base=0):
         out = []
-        for slot, p in enumerate(paths):
+        for i, p in enumerate(paths):
             b = self._board(p)
             res, cp, legal = b.result, b.current_player(), b.legal_actions()
-            # the leaf slot is a copy of the root slot: episode 0, policy keyed by the slot's global id
-            b.rollout(seed, self.first + slot, self.n * self.n - 3, False)
+            # the leaf slot (base + i) is a copy of the root slot: episode 0, policy keyed by the slot's global id
+            b.rollout(seed, self.first + base + i, self.n * self.n - 3, False)
             out.append((res, cp, legal if res == 0 else [], b.result))
         return out
 

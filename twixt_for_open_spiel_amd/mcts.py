@@ -44,18 +44,19 @@ class DeviceEvaluator:
         mask, _ = self.env.legal_mask([self.root])
         return int(res[0]), int(cp[0]), _mask_to_actions(mask.cpu().numpy().view(np.uint32)[0], self.n)
 
-    def evaluate(self, paths, seed):
-        """paths: list of action lists from the root.  Returns per leaf
-        (result after the path, player to move, legal actions, play-out result)."""
+    def evaluate(self, paths, seed, base=0):
+        """paths: list of action lists from the root; leaf i is rebuilt in slot base + i (its
+        policy key).  Returns per leaf (result after the path, player to move, legal actions,
+        play-out result)."""
         torch = self.torch
         k = len(paths)
-        assert k <= self.L
-        ids = torch.arange(k, dtype=torch.int32, device=self.env.device)
+        assert base + k <= self.L
+        ids = torch.arange(base, base + k, dtype=torch.int32, device=self.env.device)
         self.env.copy_boards(ids, self.env, torch.full((k,), self.root, dtype=torch.int32))
         depth = max((len(p) for p in paths), default=0)
         for t in range(depth):
             rows = [i for i, p in enumerate(paths) if len(p) > t]
-            st = self.env.step([paths[i][t] for i in rows], ids=rows)
+            st = self.env.step([paths[i][t] for i in rows], ids=[base + i for i in rows])
             assert not (st & 4).any(), "tree path contains an illegal move"
         res, _, cp = self.env.status(ids)
         mask, _ = self.env.legal_mask(ids)
@@ -132,19 +133,33 @@ class BatchedMCTS:
         root = Node(None, None, None)
         root.children, root.legal = {}, list(root_legal)
         root.player = root_player
-        done = 0
-        while done < max_simulations:
-            k = min(self.L, max_simulations - done)
-            picks = [self._select(root) for _ in range(k)]
-            out = self.ev.evaluate([p for _, p in picks], self.seed + self.batches)
+        # The leaves of a round trip go out in two half-batches ("lanes"), and a lane's results are
+        # applied only after the next lane has been selected -- launch(0), launch(1), finish(0),
+        # launch(2), finish(1), ...: the order in which spiel_adapter/mcts_driver.cc overlaps the
+        # device with the tree work.  Here a lane is simply evaluated when it is finished.
+        lane_leaves = self.L // 2 if self.L >= 2 else self.L
+        flying, launched, lane = [], 0, 0
+
+        def launch():
+            nonlocal launched, lane
+            k = min(lane_leaves, max_simulations - launched)
+            flying.append(([self._select(root) for _ in range(k)], self.seed + self.batches, lane * lane_leaves))
             self.batches += 1
+            launched += k
+            lane ^= 1
+
+        launch()
+        while flying:
+            if launched < max_simulations:
+                launch()
+            picks, seed, base = flying.pop(0)
+            out = self.ev.evaluate([p for _, p in picks], seed, base)
             for (leaf, _), (res, cp, legal, final) in zip(picks, out):
                 if res != 0:
                     leaf.terminal = res
                 elif leaf.children is None:
                     leaf.children, leaf.legal, leaf.player = {}, legal, cp
                 self._backup(leaf, res if res != 0 else final)
-            done += k
         visits = {a: ch.N for a, ch in root.children.items()}
         best = max(sorted(visits), key=lambda a: visits[a])
         return best, visits

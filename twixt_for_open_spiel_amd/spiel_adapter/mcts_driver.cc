@@ -9,6 +9,11 @@
 //     -Ltwixt_for_open_spiel_amd -ltwixt_hip -L/opt/rocm/lib -lamdhip64 -o mcts_driver
 //   ./mcts_driver [board_size=12] [max_simulations=20000] [moves=0 (whole game)] [leaves=2048] [seed=1] [games=1]
 //
+// The leaves of a round trip go out in two half-batches ("lanes"): while the device works on one, the
+// host selects the leaves of the other and backs the previous one up -- the order
+// launch(0), launch(1), finish(0), launch(2), finish(1), ... is fixed, so the search stays deterministic
+// (mcts.py BatchedMCTS.search follows the same order).
+//
 // games > 1: that many independent self-play games at once (self-play data generation).  Every
 // game has its own tree and root slot; the `leaves` of a device round trip are shared evenly,
 // the trees are worked on by one host thread each (OpenMP), the device work of all games goes
@@ -18,6 +23,7 @@
 #include <immintrin.h>
 #endif
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -97,7 +103,7 @@ struct Node {
 struct Leaf { int result, player; std::vector<int> legal; int final_result; };
 
 // wall-clock shares of a run (printed at the end): tree work on the host vs device round trips
-static double g_t[7];  // select, path replay, leaf query, play-outs, backup, new trees, batch assembly
+static double g_t[7];  // select, queueing a lane, waiting for a lane, parsing its results (CPU evaluator: play-outs), backup, new trees, batch assembly
 struct Timer {
   int slot;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -111,7 +117,9 @@ struct Timer {
 #ifdef MCTS_EVALUATOR_HEADER
 #include MCTS_EVALUATOR_HEADER
 #else
-// slots 0..L-1 are scratch leaves, slots L..L+G-1 the roots of the G games (mcts.py: DeviceEvaluator)
+// slots 0..L-1 are scratch leaves (lane l owns slots l*L/2 ...), slots L..L+G-1 the roots of the G games
+// (mcts.py: DeviceEvaluator).  A lane's inputs and outputs live in mapped pinned host memory that the
+// kernels read and write in place: Launch() only enqueues, Wait() waits for the lane's event.
 class Device {
  public:
   Device(int n, int leaves, int games, int threads)
@@ -119,7 +127,6 @@ class Device {
     const int cap = L_ + G_;
     TWX(twx_create(n, cap, 0, 0, &env_));
     HIP(hipMalloc(&d_ids_, 4 * cap));
-    HIP(hipMalloc(&d_src_, 4 * cap));
     HIP(hipMalloc(&d_act_, 4 * cap));
     HIP(hipMalloc(&d_st_, cap));
     HIP(hipMalloc(&d_res_, cap));
@@ -129,11 +136,26 @@ class Device {
     std::vector<int32_t> iota(cap);
     for (int i = 0; i < cap; i++) iota[i] = i;
     HIP(hipMemcpy(d_iota_, iota.data(), 4 * cap, hipMemcpyHostToDevice));
+    for (auto &ln : lane_) HIP(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
   }
-  ~Device() { twx_destroy(env_); }
+  ~Device() {
+    for (auto &ln : lane_) { if (ln.pin) (void)hipHostFree(ln.pin); (void)hipEventDestroy(ln.done); }
+    twx_destroy(env_);
+  }
+  int LaneLeaves() const { return L_ >= 2 ? L_ / 2 : L_; }  // leaves one lane takes
 
   void ResetRoots() { TWX(twx_reset_boards(env_, d_iota_ + L_, G_, nullptr)); }
-  std::vector<Leaf> RootInfos() { return Query(d_iota_ + L_, G_); }
+  std::vector<Leaf> RootInfos() {
+    TWX(twx_status_boards(env_, d_iota_ + L_, G_, d_res_, nullptr, d_cp_, nullptr));
+    TWX(twx_legal_mask_boards(env_, d_iota_ + L_, G_, d_mask_, nullptr, nullptr));
+    std::vector<uint8_t> res(G_);
+    std::vector<int8_t> cp(G_);
+    std::vector<uint32_t> mask((size_t)W_ * G_);
+    HIP(hipMemcpy(res.data(), d_res_, G_, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(cp.data(), d_cp_, G_, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(mask.data(), d_mask_, 4 * (size_t)W_ * G_, hipMemcpyDeviceToHost));
+    return Parse(res.data(), cp.data(), mask.data(), G_);
+  }
   // one move per listed game; returns nothing: the next RootInfos() tells the results
   void AdvanceRoots(const std::vector<int> &games, const std::vector<int> &actions) {
     if (games.empty()) return;
@@ -147,53 +169,65 @@ class Device {
     for (size_t i = 0; i < st.size(); i++)
       if (st[i] & TWX_ST_ILLEGAL) { std::fprintf(stderr, "illegal root move %d\n", actions[i]); std::exit(1); }
   }
-  // paths[i]: actions from the root of game game_of[i] to leaf i
-  std::vector<Leaf> Evaluate(const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of,
-                             uint32_t seed) {
-    const int k = (int)paths.size();
-    std::unique_ptr<Timer> tm(new Timer(1));
-    std::vector<int32_t> rows(k), acts;
-    for (int i = 0; i < k; i++) rows[i] = L_ + game_of[i];
-    HIP(hipMemcpy(d_src_, rows.data(), 4 * k, hipMemcpyHostToDevice));
-    TWX(twx_copy_boards(env_, d_iota_, env_, d_src_, k, nullptr));  // roots -> slots 0..k-1
-    size_t depth = 0;
-    for (auto &p : paths) depth = std::max(depth, p.size());
-    for (size_t t = 0; t < depth; t++) {
-      rows.clear();
-      acts.clear();
-      for (int i = 0; i < k; i++)
-        if (paths[i].size() > t) { rows.push_back(i); acts.push_back(paths[i][t]); }
-      HIP(hipMemcpy(d_ids_, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice));
-      HIP(hipMemcpy(d_act_, acts.data(), 4 * acts.size(), hipMemcpyHostToDevice));
-      TWX(twx_step_boards(env_, d_ids_, (int64_t)rows.size(), d_act_, nullptr, nullptr));
+  // paths[i]: actions from the root of game game_of[i] to leaf i of this lane (slot base + i).  Queues the
+  // whole evaluation -- roots -> slots, the paths level by level, status and legal masks of the leaves,
+  // the play-outs -- and returns; the lane's buffers must not be touched before Wait(lane).
+  void Launch(int lane, const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of, uint32_t seed) {
+    Timer tm(1);
+    Lane &ln = lane_[lane];
+    const int k = (int)paths.size(), base = lane * LaneLeaves();
+    size_t steps = 0, depth = 0;
+    for (auto &p : paths) { steps += p.size(); depth = std::max(depth, p.size()); }
+    // layout of the lane's block: src[k] | rows[steps] | acts[steps] | res[k] cp[k] st[k] (bytes) | mask[k*W]
+    const size_t o_rows = 4 * (size_t)k, o_acts = o_rows + 4 * steps, o_res = o_acts + 4 * steps, o_cp = o_res + k,
+                 o_st = o_cp + k, o_mask = (o_st + k + 15) / 16 * 16, bytes = o_mask + 4 * (size_t)W_ * k;
+    if (bytes > ln.bytes) {
+      if (ln.pin) HIP(hipHostFree(ln.pin));
+      ln.bytes = bytes + bytes / 2;
+      HIP(hipHostMalloc(&ln.pin, ln.bytes, hipHostMallocMapped));
+      void *d = nullptr;
+      HIP(hipHostGetDevicePointer(&d, ln.pin, 0));
+      ln.dev = static_cast<char *>(d);
     }
-    tm.reset(new Timer(2));
-    // status and legal masks of the leaves, then the play-outs, all queued before the first
-    // read-back (the play-outs do not touch the query buffers)
-    TWX(twx_status_boards(env_, d_iota_, k, d_res_, nullptr, d_cp_, nullptr));
-    TWX(twx_legal_mask_boards(env_, d_iota_, k, d_mask_, nullptr, nullptr));
-    TWX(twx_random_rollout(env_, d_iota_, k, seed, n_ * n_ - 3, d_st_, nullptr));  // terminal leaves stay
-    std::vector<Leaf> out = ReadQuery(k);
-    tm.reset(new Timer(3));
-    std::vector<uint8_t> st(k);
-    HIP(hipMemcpy(st.data(), d_st_, k, hipMemcpyDeviceToHost));
-    for (int i = 0; i < k; i++) out[i].final_result = st[i] & TWX_ST_RESULT_MASK;
+    ln.k = k; ln.o_res = o_res; ln.o_cp = o_cp; ln.o_st = o_st; ln.o_mask = o_mask;
+    char *h = static_cast<char *>(ln.pin);
+    int32_t *src = reinterpret_cast<int32_t *>(h), *rows = reinterpret_cast<int32_t *>(h + o_rows),
+            *acts = reinterpret_cast<int32_t *>(h + o_acts);
+    for (int i = 0; i < k; i++) src[i] = L_ + game_of[i];
+    const int32_t *slots = d_iota_ + base;
+    TWX(twx_copy_boards(env_, slots, env_, reinterpret_cast<const int32_t *>(ln.dev), k, nullptr));  // roots -> slots
+    size_t at = 0;
+    for (size_t t = 0; t < depth; t++) {
+      const size_t first = at;
+      for (int i = 0; i < k; i++)
+        if (paths[i].size() > t) { rows[at] = base + i; acts[at] = paths[i][t]; at++; }
+      TWX(twx_step_boards(env_, reinterpret_cast<const int32_t *>(ln.dev + o_rows) + first, (int64_t)(at - first),
+                          reinterpret_cast<const int32_t *>(ln.dev + o_acts) + first, nullptr, nullptr));
+    }
+    // (the play-outs do not touch the query results)
+    TWX(twx_status_boards(env_, slots, k, reinterpret_cast<uint8_t *>(ln.dev + o_res), nullptr,
+                          reinterpret_cast<int8_t *>(ln.dev + o_cp), nullptr));
+    TWX(twx_legal_mask_boards(env_, slots, k, reinterpret_cast<uint32_t *>(ln.dev + o_mask), nullptr, nullptr));
+    TWX(twx_random_rollout(env_, slots, k, seed, n_ * n_ - 3, reinterpret_cast<uint8_t *>(ln.dev + o_st), nullptr));  // terminal leaves stay
+    HIP(hipEventRecord(ln.done, nullptr));
+  }
+  std::vector<Leaf> Wait(int lane) {
+    Lane &ln = lane_[lane];
+    {
+      Timer tm(2);
+      HIP(hipEventSynchronize(ln.done));
+    }
+    Timer tm(3);
+    const char *h = static_cast<const char *>(ln.pin);
+    std::vector<Leaf> out = Parse(reinterpret_cast<const uint8_t *>(h + ln.o_res), reinterpret_cast<const int8_t *>(h + ln.o_cp),
+                                  reinterpret_cast<const uint32_t *>(h + ln.o_mask), ln.k);
+    const uint8_t *st = reinterpret_cast<const uint8_t *>(h + ln.o_st);
+    for (int i = 0; i < ln.k; i++) out[i].final_result = st[i] & TWX_ST_RESULT_MASK;
     return out;
   }
 
  private:
-  std::vector<Leaf> Query(const int32_t *ids, int k) {
-    TWX(twx_status_boards(env_, ids, k, d_res_, nullptr, d_cp_, nullptr));
-    TWX(twx_legal_mask_boards(env_, ids, k, d_mask_, nullptr, nullptr));
-    return ReadQuery(k);
-  }
-  std::vector<Leaf> ReadQuery(int k) {
-    std::vector<uint8_t> res(k);
-    std::vector<int8_t> cp(k);
-    std::vector<uint32_t> mask((size_t)W_ * k);
-    HIP(hipMemcpy(res.data(), d_res_, k, hipMemcpyDeviceToHost));
-    HIP(hipMemcpy(cp.data(), d_cp_, k, hipMemcpyDeviceToHost));
-    HIP(hipMemcpy(mask.data(), d_mask_, 4 * (size_t)W_ * k, hipMemcpyDeviceToHost));
+  std::vector<Leaf> Parse(const uint8_t *res, const int8_t *cp, const uint32_t *mask, int k) {
     std::vector<Leaf> out(k);
 #pragma omp parallel for schedule(static) num_threads(threads_) if (threads_ > 1 && k >= 1024)
     for (int i = 0; i < k; i++) {
@@ -208,12 +242,20 @@ class Device {
     }
     return out;
   }
+  struct Lane {
+    void *pin = nullptr;
+    char *dev = nullptr;
+    size_t bytes = 0, o_res = 0, o_cp = 0, o_st = 0, o_mask = 0;
+    int k = 0;
+    hipEvent_t done{};
+  };
   int n_, L_, G_, W_, threads_;
   twx_env *env_ = nullptr;
-  int32_t *d_ids_, *d_src_, *d_act_, *d_iota_;
+  int32_t *d_ids_, *d_act_, *d_iota_;
   uint8_t *d_st_, *d_res_;
   int8_t *d_cp_;
   uint32_t *d_mask_;
+  Lane lane_[2];
 };
 #endif  // MCTS_EVALUATOR_HEADER
 
@@ -351,7 +393,6 @@ int main(int argc, char **argv) {
   const uint32_t seed = argc > 5 ? (uint32_t)std::atol(argv[5]) : 1u;
   const int games = argc > 6 ? std::atoi(argv[6]) : 1;
   if (games < 1 || leaves < games) { std::fprintf(stderr, "need 1 <= games <= leaves\n"); return 1; }
-  const long per_game = leaves / games;  // leaves of one game per device round trip
   const int threads = std::min(games, HostCores());
   Device dev(n, leaves, games, threads);
   dev.ResetRoots();
@@ -373,31 +414,46 @@ int main(int argc, char **argv) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (nl > 1)
       for (int j = 0; j < nl; j++) mcts[live[j]].Begin(info[live[j]].player, info[live[j]].legal);
     }
-    for (long done = 0; done < sims;) {
-      const long k = std::min<long>(per_game, sims - done);
-      std::vector<std::vector<Node *>> leaf(nl);
+    // two lanes in flight: launch(0), launch(1), finish(0), launch(2), finish(1), ...
+    struct InFlight { int lane; long k; std::vector<std::vector<Node *>> leaf; };
+    std::vector<InFlight> flying;  // oldest first, at most two
+    const long per_lane = std::max<long>(1, dev.LaneLeaves() / games);
+    long launched = 0;
+    int next_lane = 0;
+    auto launch = [&]() {
+      InFlight f;
+      f.lane = next_lane;
+      next_lane ^= 1;
+      f.k = std::min<long>(per_lane, sims - launched);
+      f.leaf.resize(nl);
       std::vector<std::vector<std::vector<int>>> path(nl);
       {
         Timer tm(0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (nl > 1)
-        for (int j = 0; j < nl; j++) mcts[live[j]].SelectBatch(k, &leaf[j], &path[j]);
+        for (int j = 0; j < nl; j++) mcts[live[j]].SelectBatch(f.k, &f.leaf[j], &path[j]);
       }
       std::vector<std::vector<int>> paths;
       std::vector<int> game_of;
       {
         Timer tm(6);
-        paths.reserve(nl * k);
-        game_of.reserve(nl * k);
+        paths.reserve(nl * f.k);
+        game_of.reserve(nl * f.k);
         for (int j = 0; j < nl; j++)
-          for (long i = 0; i < k; i++) { paths.push_back(std::move(path[j][i])); game_of.push_back(live[j]); }
+          for (long i = 0; i < f.k; i++) { paths.push_back(std::move(path[j][i])); game_of.push_back(live[j]); }
       }
-      std::vector<Leaf> out = dev.Evaluate(paths, game_of, seed + (uint32_t)batches++);
-      {
-        Timer tm(4);
+      dev.Launch(f.lane, paths, game_of, seed + (uint32_t)batches++);
+      launched += f.k;
+      flying.push_back(std::move(f));
+    };
+    launch();
+    while (!flying.empty()) {
+      if (launched < sims) launch();
+      InFlight f = std::move(flying.front());
+      flying.erase(flying.begin());
+      std::vector<Leaf> out = dev.Wait(f.lane);
+      Timer tm(4);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (nl > 1)
-        for (int j = 0; j < nl; j++) mcts[live[j]].ApplyBatch(leaf[j].data(), out.data() + (size_t)j * k, k);
-      }
-      done += k;
+      for (int j = 0; j < nl; j++) mcts[live[j]].ApplyBatch(f.leaf[j].data(), out.data() + (size_t)j * f.k, f.k);
     }
     std::vector<int> acts;
     for (int g : live) {
@@ -417,7 +473,8 @@ int main(int argc, char **argv) {
                 moves[g]);
   std::printf("%ld simulations in %.2f s = %.0f simulations/s (%d game%s, %d leaves per round trip, %d host thread%s)\n",
               total, dt, total / dt, games, games == 1 ? "" : "s", leaves, threads, threads == 1 ? "" : "s");
-  std::printf("time: select %.2f s, path replay %.2f s, leaf query %.2f s, play-outs %.2f s, backup %.2f s, "
-              "new trees %.2f s, batch assembly %.2f s\n", g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5], g_t[6]);
+  std::printf("time: select %.2f s, queueing the lanes %.2f s, waiting for them %.2f s, results / play-outs %.2f s, "
+              "backup %.2f s, new trees %.2f s, batch assembly %.2f s\n", g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5],
+              g_t[6]);
   return 0;
 }
