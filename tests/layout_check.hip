@@ -1,0 +1,59 @@
+// tests/layout_check.hip -- host-side check of the engine's address arithmetic (CPU test, no GPU):
+// chunk_index / journal_word_index (where a board's chunks and journal records live in the tiled
+// state array) and reversed_batch (the backward batch order that keeps every batch on its XCD label),
+// compiled from the product header.  Prints "OK" or the first violation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <set>
+#include <vector>
+
+#include "../twixt_for_open_spiel_amd/csrc/twixt_geom.h"
+#include "../twixt_for_open_spiel_amd/csrc/twixt_device_common.h"
+
+#define CHECK(c, ...) do { if (!(c)) { printf("FAIL %s:%d %s: ", __FILE__, __LINE__, #c); printf(__VA_ARGS__); printf("\n"); return 1; } } while (0)
+
+int main() {
+  // ---- state layout: every (board, chunk) and every (board, journal slot) has its own place inside
+  //      the board's tile; the journal of a tile is its last two chunk rows, [slot][board] ----
+  for (int n = 5; n <= 24; n++) {
+    const int W = (n * n + 31) / 32, CH = 2 * W + 1, CHT = CH + twx::kJournalChunks, ts = tile_shift(CHT);
+    CHECK(ts == (n >= 19 ? 5 : 6), "n=%d ts=%d", n, ts);
+    const long TB = 1L << ts, boards = 5 * TB;  // five tiles
+    std::vector<int> owner((size_t)boards * CHT * 4, 0);  // per dword of the state array: times claimed
+    for (long b = 0; b < boards; b++) {
+      for (int c = 0; c < CH; c++) {
+        const long ci = chunk_index(c, b, ts, CHT);
+        CHECK(ci >= 0 && ci < boards * CHT, "n=%d chunk index %ld", n, ci);
+        CHECK(ci / (CHT * TB) == b / TB, "n=%d: chunk %d of board %ld outside its tile", n, c, b);
+        CHECK((ci % (CHT * TB)) / TB == c && ci % TB == b % TB, "n=%d: chunk row / slot of board %ld", n, b);
+        for (int k = 0; k < 4; k++) owner[ci * 4 + k]++;
+      }
+      for (int s = 0; s < twx::kJournalSlots; s++) {
+        const long wi = journal_word_index(s, b, ts, CHT);
+        CHECK(wi >= 0 && wi < boards * CHT * 4, "n=%d journal word %ld", n, wi);
+        const long tile = wi / (CHT * TB * 4), in_tile = wi % (CHT * TB * 4);
+        CHECK(tile == b / TB, "n=%d: record of board %ld outside its tile", n, b);
+        CHECK(in_tile >= (long)CH * TB * 4, "n=%d: record inside the planes", n);
+        CHECK((in_tile - (long)CH * TB * 4) / TB == s && in_tile % TB == b % TB, "n=%d: [slot][board] order", n);
+        owner[wi]++;
+      }
+    }
+    for (size_t i = 0; i < owner.size(); i++) CHECK(owner[i] == 1, "n=%d: dword %zu claimed %d times", n, i, owner[i]);
+  }
+  // ---- backward batch order: a bijection that reverses blocks of 8 and keeps i % 8 ----
+  for (long nb : {1L, 7L, 8L, 9L, 16L, 37L, 64L, 1000L, 16384L, 32768L, 32771L}) {
+    std::set<long> seen;
+    const long q = nb & ~7L;
+    for (long i = 0; i < nb; i++) {
+      const long t = reversed_batch(i, nb);
+      CHECK(t >= 0 && t < nb, "nbatch=%ld: %ld -> %ld", nb, i, t);
+      CHECK(seen.insert(t).second, "nbatch=%ld: %ld taken twice", nb, t);
+      CHECK(t % 8 == i % 8, "nbatch=%ld: batch %ld moves to another XCD label in the backward walk (%ld)", nb, t, i);
+      if (i < q) CHECK(t / 8 == (q - 1 - i) / 8, "nbatch=%ld: blocks of 8 not reversed", nb);
+      else CHECK(t == i, "nbatch=%ld: the ragged last block moved", nb);
+    }
+  }
+  printf("OK\n");
+  return 0;
+}

@@ -99,6 +99,9 @@ __device__ unsigned long long g_stamps[16];
 // CHT KiB block per wave, whole DRAM pages) for the boards up to N = 18; ts = 5 for N >= 19, whose
 // whole-batch kernel works on 32 boards per wave (twixt_pair_kernel.h): with 64-board tiles its
 // waves read interleaved 512-byte halves of every row and the bare read stream ran 6 % slower.
+#ifndef TWX_SMALL_CHT
+#define TWX_SMALL_CHT 25  // (twixt_engine.hip sets it first and says how it was measured)
+#endif
 constexpr int tile_shift(int cht) { return cht > TWX_SMALL_CHT ? 5 : 6; }
 __host__ __device__ __forceinline__ long chunk_index(long c, long b, int ts, int cht) {
   return (((b >> ts) * cht + c) << ts) + (b & ((1L << ts) - 1));
@@ -220,7 +223,7 @@ constexpr int kTicketGroups = TWX_TICKET_GROUPS, kTicketStride = 64;
 // last).  A board's lines are then asked for by the same XCD in every launch: +1.2 % at N=24, +7..8 %
 // at N=19..21, every size gains (profiles/r02_xcd_order_ab.txt; a memory-side effect: the L2 hit
 // counts do not change).
-__device__ __forceinline__ long reversed_batch(long i, long nbatch) {
+__host__ __device__ __forceinline__ long reversed_batch(long i, long nbatch) {
   const long q = nbatch & ~7L;
   return i < q ? (((q - 1 - i) & ~7L) | (i & 7L)) : i;
 }
