@@ -64,3 +64,15 @@ def test_adapter_reference_tests_and_playthrough(tmp_path):
             assert [float(meta[4]), float(meta[5])] == [float(v) for v in st["returns"]]
             seen += 1
     assert seen == 9
+
+
+@pytest.mark.gpu
+def test_example_script_plays_a_whole_game():
+    """BASELINE config 1 (plumbing): examples/example.py plays one random N=8 game on the engine
+    and prints every state; the game must end with a result line."""
+    out = subprocess.run([os.sys.executable, os.path.join(ROOT, "examples", "example.py"), "--no-color", "--seed", "3"],
+                         capture_output=True, timeout=300)
+    text = out.stdout.decode("latin-1")
+    assert out.returncode == 0, text[-1500:] + out.stderr.decode()[-1500:]
+    assert text.startswith("Initial state:") and text.rstrip().splitlines()[-1].startswith("Returns:")
+    assert text.count("chose action") == text.count("State:") >= 10
