@@ -40,8 +40,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   constexpr int RS = BPW * 4, GS = 2 * RS;  // chunk-row / word-group stride of the LDS image in dwords
   constexpr int NJ = CHT;                   // 16-byte registers a lane prefetches
 #define plane_off(p) ((((p) >> 2) * RS) + ((p) & 3))
-  constexpr int oR = plane_off(twx::kPlaneRed), oL0 = plane_off(twx::kPlaneLink0),
-                oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
+  constexpr int oR = plane_off(twx::kPlaneRed), oS = plane_off(twx::kPlaneStart), oE = plane_off(twx::kPlaneEnd);
   constexpr uint32_t kColMask = (1u << N) - 1u;
   static_assert(oE == oS + 1 && (oS & 1) == 0 && (plane_off(twx::kPlaneLink0) & 1) == 0 && (plane_off(twx::kPlaneLink0 + 2) & 1) == 0,
                 "lds_or2 pairs: adjacent, 8-byte aligned planes");
