@@ -141,8 +141,11 @@ def measured_traffic(n, batch):
         src["rejected"] = "measured for N=%s, B=%s" % (js.get("board_size"), js.get("batch"))
     elif active_knobs():
         src["rejected"] = "tuning knobs set: " + ",".join(active_knobs())
-    elif js.get("source_stamp") != src["source_stamp_now"] and js.get("lib_sha256") != src["lib_sha256_now"]:
-        src["rejected"] = "measured on another build of libtwixt_hip.so"
+    elif js.get("lib_sha256") != src["lib_sha256_now"]:
+        # the binary that runs decides: a stale .so built from other sources must not borrow the
+        # traffic of the build the sources on disk would give (build() skips by mtime)
+        src["rejected"] = "measured on another build of libtwixt_hip.so (library hash differs; sources %s)" % (
+            "match" if js.get("source_stamp") == src["source_stamp_now"] else "differ too")
     else:
         return float(js["hbm_bytes_per_launch"]), src
     return None, src

@@ -31,10 +31,17 @@ class Device {
         std::exit(1);
       }
   }
-  int LaneLeaves() const { return L_ >= 2 ? L_ / 2 : L_; }
+  // (the driver's rule: the lanes split the leaf slots only while each half holds a leaf of every game)
+  int Games() const { return (int)roots_.size(); }
+  int LaneLeaves() const { return L_ >= 2 * Games() ? L_ / 2 : L_; }
+  int LaneBase(int lane) const { return L_ >= 2 * Games() ? lane * (L_ / 2) : 0; }
   // the driver's two-lane interface: here the lane is evaluated on the spot and handed over by Wait()
   void Launch(int lane, const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of, uint32_t seed) {
-    const int k = (int)paths.size(), base = lane * LaneLeaves();
+    const int k = (int)paths.size(), base = LaneBase(lane);
+    if (base + k > L_) {
+      std::fprintf(stderr, "lane %d: %d leaves from slot %d do not fit %d leaf slots\n", lane, k, base, L_);
+      std::exit(1);
+    }
     std::vector<Leaf> &out = lane_out_[lane];
     out.assign(k, Leaf());
     Timer tm(3);

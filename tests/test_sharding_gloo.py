@@ -104,7 +104,8 @@ def test_roofline_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
     library, workload and knobs it was measured on."""
     import bench
     from twixt_for_open_spiel_amd import build as b
-    good = {"source_stamp": b.source_stamp(), "lib_sha256": "x", "board_size": 24, "batch": 1 << 20,
+    b.build()
+    good = {"source_stamp": b.source_stamp(), "lib_sha256": b.lib_stamp(), "board_size": 24, "batch": 1 << 20,
             "hbm_bytes_per_launch": 8.0e8, "method": "m"}
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
@@ -120,9 +121,14 @@ def test_roofline_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
     t, src = bench.measured_traffic(24, 1 << 20)
     assert t is None and "TWX_JOURNAL_PERIOD" in src["rejected"]
     monkeypatch.delenv("TWX_JOURNAL_PERIOD")
-    path.write_text(json.dumps(dict(good, source_stamp="0" * 16)))  # another build
+    # the binary that runs decides: a library other than the measured one is refused even when
+    # the sources on disk hash to the measured stamp (build() skips by mtime, so a stale .so can sit there)
+    path.write_text(json.dumps(dict(good, lib_sha256="0" * 16)))
     t, src = bench.measured_traffic(24, 1 << 20)
-    assert t is None and "another build" in src["rejected"]
+    assert t is None and "another build" in src["rejected"] and "sources match" in src["rejected"]
+    path.write_text(json.dumps(dict(good, lib_sha256="0" * 16, source_stamp="0" * 16)))
+    t, src = bench.measured_traffic(24, 1 << 20)
+    assert t is None and "differ too" in src["rejected"]
 
 
 def test_design_byte_model():

@@ -509,7 +509,7 @@ int twx_reset_boards(twx_env *e, const int32_t *ids, int64_t n, void *stream) {
   if (n == 0) return TWX_OK;
   TWX_USE(e);
   if (int rc = materialise(e, (hipStream_t)stream)) return rc;
-  const long threads = (long)e->d.CHT * n;
+  const long threads = (long)e->d.CH * n;  // planes and scalars: the journal rows are shared with the tile's other boards
   hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                      e->state, e->d, e->tables + e->init_off, ids, (long)n);
   HIP_TRY(hipGetLastError());

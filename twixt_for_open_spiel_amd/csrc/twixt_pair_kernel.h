@@ -148,7 +148,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
   const int dlt0 = up ? twx::kDX[6] * N + twx::kDY[6] : twx::kDX[4] * N + twx::kDY[4];
   const int dlt1 = up ? twx::kDX[7] * N + twx::kDY[7] : twx::kDX[5] * N + twx::kDY[5];
   const int offA = up ? oS : oR;          // first flag / peg word of a record's own cell
-  const uint32_t pm = up ? 0u : 1u;       // (the lower lane adds the player: red / blue words are adjacent)
+  const uint32_t peg_sel = up ? 0u : 1u;  // (the lower lane adds the player: red / blue words are adjacent)
   uint32_t *const me = lds + (bl << 2);   // this board's slot inside every chunk row
   uint32_t *const meh = me + (up ? WH * GS : 0);  // first word group of this lane's half
   uint32_t *const sc = me + CS * RS;      // scalars
@@ -237,7 +237,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
         if (__ballot((e & twx::kJSwap) != 0u))  // rare: undo red's first peg on a swap (tb.cc:450-455)
           lds_and(me + (move_one >> 5) * GS + oR, (e & twx::kJSwap) ? ~(1u << (move_one & 31)) : 0xffffffffu);
         // lower: the peg (red / blue words are adjacent); upper: START gained
-        lds_or(g + offA + (int)((e >> 10) & pm), bit & ((uint32_t)sbit(e, 19) | ~hm));
+        lds_or(g + offA + (int)((e >> 10) & peg_sel), bit & ((uint32_t)sbit(e, 19) | ~hm));
         lds_or(g + oE, bit & (uint32_t)sbit(e, 20) & hm);  // upper: END gained
         const uint32_t eo = e >> own_sh;  // bits 0, 1: this lane's links at the cell; bits 4, 5: at the targets
         lds_or2(g + link_lo, bit & (uint32_t)sbit(eo, 0), bit & (uint32_t)sbit(eo, 1));
@@ -272,7 +272,7 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
     //      cells: the count is taken only when some board of the wave is that full (wave-uniform) ----
     uint32_t m[WH];
     const bool count_opp = __ballot(counter + 1u >= (uint32_t)(N * (N - 2))) != 0ull;
-    int po = 0, pm = 0;
+    int n_opp = 0, n_mine = 0;
 #pragma unroll
     for (int ii = 0; ii < WH; ii++) {
       const uint2 rb = *reinterpret_cast<const uint2 *>(meh + ii * GS);
@@ -285,10 +285,10 @@ __device__ __forceinline__ void step_pair_body(uint4 *__restrict__ state, long b
       const uint32_t reg_r = r0l ^ ((r0l ^ r0u) & hm), reg_b = r1l ^ ((r1l ^ r1u) & hm);
       // (move 1, blue to move: red's first peg stays legal for blue -- the swap)
       m[ii] = (player ? reg_b : reg_r) & ~((counter == 1u) ? rb.y : occ);
-      pm += __popc(m[ii]);
-      if (count_opp) po += __popc((player ? reg_r : reg_b) & ~occ);
+      n_mine += __popc(m[ii]);
+      if (count_opp) n_opp += __popc((player ? reg_r : reg_b) & ~occ);
     }
-    const PairVal pc = pair_swap((uint32_t)pm | ((uint32_t)po << 10));
+    const PairVal pc = pair_swap((uint32_t)n_mine | ((uint32_t)n_opp << 10));
     const int cnt_lo = (int)(pc.lo & 1023u), cnt = cnt_lo + (int)(pc.hi & 1023u);
     const int cnt_opp = count_opp ? (int)((pc.lo >> 10) + (pc.hi >> 10)) : (1 << 20);  // "plenty": no draw
 

@@ -30,7 +30,10 @@ __global__ void reset_kernel(uint4 *state, Dims d, const uint32_t *init, const i
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long j = t % (ids ? n : d.bpad);
   const int c = (int)(t / (ids ? n : d.bpad));
-  if (c >= d.CHT) return;
+  // A whole-batch reset clears the journal rows too.  A listed-boards reset must NOT: "chunk" CH or
+  // CH + 1 at board b's position of a [slot][board] journal row is one slot's records of FOUR boards
+  // of the tile, not b's own journal; planes and scalars (journal base 0) are all a board owns.
+  if (c >= (ids ? d.CH : d.CHT)) return;
   long b = j;
   if (ids) {
     b = ids[j];

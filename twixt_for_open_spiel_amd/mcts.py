@@ -137,13 +137,17 @@ class BatchedMCTS:
         # applied only after the next lane has been selected -- launch(0), launch(1), finish(0),
         # launch(2), finish(1), ...: the order in which spiel_adapter/mcts_driver.cc overlaps the
         # device with the tree work.  Here a lane is simply evaluated when it is finished.
-        lane_leaves = self.L // 2 if self.L >= 2 else self.L
+        # (with a single leaf slot there is nothing to split: both lanes use slot 0, as the driver does
+        # whenever a half would not hold a leaf of every game)
+        split = self.L >= 2
+        lane_leaves = self.L // 2 if split else self.L
         flying, launched, lane = [], 0, 0
 
         def launch():
             nonlocal launched, lane
             k = min(lane_leaves, max_simulations - launched)
-            flying.append(([self._select(root) for _ in range(k)], self.seed + self.batches, lane * lane_leaves))
+            flying.append(([self._select(root) for _ in range(k)], self.seed + self.batches,
+                           lane * lane_leaves if split else 0))
             self.batches += 1
             launched += k
             lane ^= 1

@@ -120,6 +120,11 @@ struct Timer {
 // slots 0..L-1 are scratch leaves (lane l owns slots l*L/2 ...), slots L..L+G-1 the roots of the G games
 // (mcts.py: DeviceEvaluator).  A lane's inputs and outputs live in mapped pinned host memory that the
 // kernels read and write in place: Launch() only enqueues, Wait() waits for the lane's event.
+// The leaf slots are split between the lanes only while each half still holds a leaf of every game
+// (L >= 2G); below that both lanes use ALL L slots, one evaluation after the other (the stream is in
+// order and a lane's results have left the slots when the next evaluation overwrites them), so a lane
+// never reaches into the root slots L.. (the same rule: LaneSlots in tests/mcts_cpu_evaluator.h,
+// BatchedMCTS.search in mcts.py).
 class Device {
  public:
   Device(int n, int leaves, int games, int threads)
@@ -142,7 +147,8 @@ class Device {
     for (auto &ln : lane_) { if (ln.pin) (void)hipHostFree(ln.pin); (void)hipEventDestroy(ln.done); }
     twx_destroy(env_);
   }
-  int LaneLeaves() const { return L_ >= 2 ? L_ / 2 : L_; }  // leaves one lane takes
+  int LaneLeaves() const { return L_ >= 2 * G_ ? L_ / 2 : L_; }               // leaves one lane takes
+  int LaneBase(int lane) const { return L_ >= 2 * G_ ? lane * (L_ / 2) : 0; }  // its first slot
 
   void ResetRoots() { TWX(twx_reset_boards(env_, d_iota_ + L_, G_, nullptr)); }
   std::vector<Leaf> RootInfos() {
@@ -175,7 +181,11 @@ class Device {
   void Launch(int lane, const std::vector<std::vector<int>> &paths, const std::vector<int> &game_of, uint32_t seed) {
     Timer tm(1);
     Lane &ln = lane_[lane];
-    const int k = (int)paths.size(), base = lane * LaneLeaves();
+    const int k = (int)paths.size(), base = LaneBase(lane);
+    if (k < 0 || base + k > L_) {  // the slots from L_ on hold the games' roots
+      std::fprintf(stderr, "lane %d: %d leaves from slot %d do not fit %d leaf slots\n", lane, k, base, L_);
+      std::exit(1);
+    }
     size_t steps = 0, depth = 0;
     for (auto &p : paths) { steps += p.size(); depth = std::max(depth, p.size()); }
     // layout of the lane's block: src[k] | rows[steps] | acts[steps] | res[k] cp[k] st[k] (bytes) | mask[k*W]
