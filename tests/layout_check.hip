@@ -41,6 +41,40 @@ int main() {
     }
     for (size_t i = 0; i < owner.size(); i++) CHECK(owner[i] == 1, "n=%d: dword %zu claimed %d times", n, i, owner[i]);
   }
+  // ---- split layout (the big boards, step_window_kernel): every word of every plane, every scalar and
+  //      every journal record of a board has its own dword inside the board's tile; pegs / scalars /
+  //      journal in [row][board] rows of 512 B, links + flags board-major behind them ----
+  for (int n = 19; n <= 24; n++) {
+    const int W = (n * n + 31) / 32, RP = split_peg_rows(W), RA = split_rows(W), LFB = split_lf_bytes(W);
+    const long TD = split_tile_bytes(W) / 4, boards = 5 * 32;
+    CHECK(split_tile_bytes(W) % 128 == 0 || n != 24, "n=24 tiles are whole 128-byte lines");
+    CHECK(LFB % 16 == 0 && LFB >= 24 * W && RA == RP + 3, "n=%d region size", n);
+    std::vector<int> owner((size_t)(boards / 32) * TD, 0);
+    for (long b = 0; b < boards; b++) {
+      for (int p = 0; p < twx::kNumPlanes; p++)
+        for (int i = 0; i < W; i++) {
+          const long wi = split_word_index(p, i, b, W);
+          CHECK(wi >= 0 && wi / TD == b / 32, "n=%d: plane %d word %d of board %ld outside its tile", n, p, i, b);
+          const long in = wi % TD;
+          if (p < 2) CHECK(in / 128 == i / 2 && (in % 128) / 4 == b % 32 && in % 4 == (i & 1) * 2 + p, "n=%d peg row", n);
+          else CHECK(in >= RA * 128 && (in - RA * 128) / (LFB / 4) == b % 32 && (in - RA * 128) % (LFB / 4) == 6 * i + p - 2, "n=%d region", n);
+          owner[wi]++;
+        }
+      for (int j = 0; j < 4; j++) {
+        const long wi = split_scalar_index(j, b, W);
+        CHECK(wi / TD == b / 32 && (wi % TD) / 128 == RP && ((wi % TD) % 128) == (b % 32) * 4 + j, "n=%d scalars", n);
+        owner[wi]++;
+      }
+      for (int s = 0; s < twx::kJournalSlots; s++) {
+        const long wi = split_journal_index(s, b, W);
+        CHECK(wi / TD == b / 32 && (wi % TD) == (long)(RP + 1) * 128 + s * 32 + b % 32, "n=%d journal [slot][board]", n);
+        owner[wi]++;
+      }
+    }
+    long claimed = 0;
+    for (size_t i = 0; i < owner.size(); i++) { CHECK(owner[i] <= 1, "n=%d: dword %zu claimed %d times", n, i, owner[i]); claimed += owner[i]; }
+    CHECK(claimed == boards * (8 * W + 4 + twx::kJournalSlots), "n=%d: %ld dwords claimed", n, claimed);
+  }
   // ---- backward batch order: a bijection that reverses blocks of 8 and keeps i % 8 ----
   for (long nb : {1L, 7L, 8L, 9L, 16L, 37L, 64L, 1000L, 16384L, 32768L, 32771L}) {
     std::set<long> seen;

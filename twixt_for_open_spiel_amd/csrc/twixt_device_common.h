@@ -114,6 +114,38 @@ __host__ __device__ __forceinline__ long chunk_index(long c, long b, int ts, int
 __host__ __device__ __forceinline__ long journal_word_index(int s, long b, int ts, int cht) {
   return ((((b >> ts) * cht + (cht - twx::kJournalChunks)) << ts) << 2) + ((long)s << ts) + (b & ((1L << ts) - 1));
 }
+// ---------------------------------------------------------------------------
+// SPLIT layout (round 3; the big boards, N >= 19, whose whole-batch step is step_window_kernel,
+// twixt_window_kernel.h).  A step needs ALL of a board's pegs (legal mask, k-th legal action) but its
+// links and border flags only in the six board columns around the move, so the two live apart:
+//   tile of 32 boards = RA rows of 512 B, [row][board] x 16 B, streamed by every launch:
+//       rows 0..RP-1   pegs     { red_2r, blue_2r, red_2r+1, blue_2r+1 }        RP = ceil(W / 2)
+//       row  RP        scalars  { s0, s1, s2, s3 }
+//       rows RP+1, +2  redo journal, 8 slots x 32 boards x 32-bit records, [slot][board]
+//   then 32 x LFB bytes BOARD-MAJOR: links + flags of board q at q * LFB, word i (cells 32i..32i+31)
+//       = 6 dwords { linkNNE_i, linkENE_i, linkESE_i, linkSSE_i, start_i, end_i }  (LFB = 24 W, rounded
+//       up to a multiple of 16)
+// so the window of a move -- board columns x-3..x+2 = at most NW consecutive words of every plane -- is
+// ONE contiguous run of about 150 bytes (two 128-byte lines) that the wave fetches after it has
+// chosen the move.  N=24: 12 rows (6 KiB) + 32 x 432 B = 19,968 B per tile, as many as the chunk layout.
+// ---------------------------------------------------------------------------
+constexpr int split_peg_rows(int W) { return (W + 1) / 2; }
+constexpr int split_rows(int W) { return split_peg_rows(W) + 1 + twx::kJournalChunks; }  // RA
+constexpr int split_lf_bytes(int W) { return (24 * W + 15) & ~15; }                      // LFB
+constexpr long split_tile_bytes(int W) { return (long)split_rows(W) * 512 + 32L * split_lf_bytes(W); }
+// dword index into the state array of: word i of plane p, scalar j, journal record s -- of board b
+__host__ __device__ __forceinline__ long split_word_index(int p, int i, long b, int W) {
+  const long tile = (b >> 5) * (split_tile_bytes(W) >> 2), q = b & 31;
+  if (p < 2) return tile + (long)(i >> 1) * 128 + q * 4 + (i & 1) * 2 + p;
+  return tile + (long)split_rows(W) * 128 + q * (split_lf_bytes(W) >> 2) + i * 6 + (p - 2);
+}
+__host__ __device__ __forceinline__ long split_scalar_index(int j, long b, int W) {
+  return (b >> 5) * (split_tile_bytes(W) >> 2) + (long)split_peg_rows(W) * 128 + (b & 31) * 4 + j;
+}
+__host__ __device__ __forceinline__ long split_journal_index(int s, long b, int W) {
+  return (b >> 5) * (split_tile_bytes(W) >> 2) + (long)(split_peg_rows(W) + 1) * 128 + (long)s * 32 + (b & 31);
+}
+
 template <bool NT>
 __device__ __forceinline__ void tile_store_word(uint32_t *p, uint32_t v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);
@@ -201,6 +233,14 @@ __device__ __forceinline__ void tile_store(uint4 *p, uint4 v) {
     __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
   } else {
     *p = v;
+  }
+}
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = B .. E-1 (instruction immediates)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
   }
 }
 __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

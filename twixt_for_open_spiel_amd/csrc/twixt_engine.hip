@@ -61,13 +61,14 @@ int fail(int code, const std::string &msg) {
 #include "twixt_device_common.h"
 #include "twixt_step_kernel.h"
 #include "twixt_pair_kernel.h"
+#include "twixt_window_kernel.h"
 #include "twixt_util_kernels.h"
 
 template <int N>
 hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                        uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
                        const int32_t *ids, long nsub, int rsteps, int rpw, uint32_t *ticket, TicketBases ticket_base,
-                       int nstatic, hipStream_t s) {
+                       int nstatic, bool split, hipStream_t s) {
   const long nbatch = ids ? (nsub + rpw - 1) / rpw : bpad / kWave;  // rpw: rows of the list per wave
   const long grid = nbatch < (long)waves ? nbatch : (long)waves;
   const size_t lds_bytes = (size_t)twx::Geo<N>::CHT * kWave * 16;  // the wave's 64 boards: 39 KiB at N=24
@@ -76,6 +77,8 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
                      actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, rpw, ticket, ticket_base, nstatic)
   if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT) {
     if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
+  } else if (split) {  // the handle's state is in the split layout (listed boards, play-outs)
+    if (ids) TWX_LAUNCH((step_kernel64<N, true, true>)); else TWX_LAUNCH((step_kernel64<N, false, true>));
   } else {
     if (ids) TWX_LAUNCH((step_kernel64<N, true>)); else TWX_LAUNCH((step_kernel64<N, false>));
   }
@@ -125,23 +128,70 @@ int pair_occupancy() {
 typedef hipError_t (*pair_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t, int, int,
                               int, uint32_t *, TicketBases, int, hipStream_t);
 
+// windowed step on the split layout (twixt_window_kernel.h): whole-batch steps of the big boards; the
+// launches that rewrite everything (compactions, flushes) run the FULL instantiation
+template <int N>
+hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
+                         uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
+                         uint32_t *ticket, TicketBases ticket_base, int nstatic, hipStream_t s) {
+  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+    const long nbatch = bpad / 32;
+    const long grid = nbatch < (long)waves ? nbatch : (long)waves;
+    const bool full = (flags & kFlagCompact) != 0;
+    const size_t lds_bytes = (size_t)WinGeo<N>::lds_bytes(full);
+    char *st = reinterpret_cast<char *>(state);
+    if (full)
+      hipLaunchKernelGGL((step_window_full_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
+                         actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
+    else
+      hipLaunchKernelGGL((step_window_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
+                         actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
+    return hipGetLastError();
+  }
+  return hipErrorInvalidConfiguration;
+}
+// resident waves per CU of the journal (0) / the rewriting (1) instantiation
+template <int N>
+int window_occupancy_j() {
+  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_kernel<N>, kWave, (size_t)WinGeo<N>::lds_bytes(false)) != hipSuccess)
+      return 0;
+    return blocks;
+  }
+  return 0;
+}
+template <int N>
+int window_occupancy_f() {
+  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_full_kernel<N>, kWave, (size_t)WinGeo<N>::lds_bytes(true)) != hipSuccess)
+      return 0;
+    return blocks;
+  }
+  return 0;
+}
+
 typedef int (*occ_fn)();
 typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t,
-                              int, int, int, const int32_t *, long, int, int, uint32_t *, TicketBases, int, hipStream_t);
+                              int, int, int, const int32_t *, long, int, int, uint32_t *, TicketBases, int, bool, hipStream_t);
 
 template <int N>
 struct StepTable {
-  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po) {
+  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po, pair_fn *w, occ_fn *wj, occ_fn *wf) {
     t[N] = &launch_step<N>;
     o[N] = &step_occupancy<N>;
     p[N] = &launch_pair<N>;
     po[N] = &pair_occupancy<N>;
-    StepTable<N - 1>::fill(t, o, p, po);
+    w[N] = &launch_window<N>;
+    wj[N] = &window_occupancy_j<N>;
+    wf[N] = &window_occupancy_f<N>;
+    StepTable<N - 1>::fill(t, o, p, po, w, wj, wf);
   }
 };
 template <>
 struct StepTable<TWX_MIN_BOARD_SIZE - 1> {
-  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *) {}
+  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *, pair_fn *, occ_fn *, occ_fn *) {}
 };
 
 struct StepTables {
@@ -149,7 +199,9 @@ struct StepTables {
   occ_fn occ[TWX_MAX_BOARD_SIZE + 1];
   pair_fn pair[TWX_MAX_BOARD_SIZE + 1];
   occ_fn pocc[TWX_MAX_BOARD_SIZE + 1];
-  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc); }
+  pair_fn window[TWX_MAX_BOARD_SIZE + 1];
+  occ_fn wocc_j[TWX_MAX_BOARD_SIZE + 1], wocc_f[TWX_MAX_BOARD_SIZE + 1];
+  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc, window, wocc_j, wocc_f); }
 };
 const StepTables &step_tables() {
   static const StepTables t;  // thread-safe static init
@@ -179,6 +231,9 @@ struct twx_env {
   int init_off;    // word offset of the initial-position chunks inside `tables`
   bool pair;       // whole-batch launches go to step_pair_kernel (two lanes per board; big boards)
   int waves_pair;  // its persistent grid
+  // split layout (d.lay = 1): whole-batch launches go to step_window_kernel; persistent grids of its journal
+  // and of its rewriting instantiation
+  int waves_win, waves_win_full;
   int cus;         // compute units of the device
   // dynamic batch order (TWX_DYNAMIC): device ticket counters (never reset) and the values
   // they will have when the next launch starts
@@ -271,9 +326,10 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   if (e->pingpong && !ids && (e->launches & 1)) flags |= kFlagReverse;
   {
     // whole-batch launches of the big boards: the two-lanes-per-board kernel
-    const bool use_pair = e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling);
+    const bool use_win = e->d.lay != 0 && !ids && rsteps == 1;
+    const bool use_pair = use_win || (e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling));
     int bpw = use_pair ? 32 : kWave;  // boards per wave
-    const int waves = use_pair ? e->waves_pair : e->waves;
+    const int waves = use_win ? ((flags & kFlagCompact) ? e->waves_win_full : e->waves_win) : use_pair ? e->waves_pair : e->waves;
     // a short list of boards is spread over many waves (rows per wave: a power of two, at least 4,
     // while that still fills four waves per CU): see step_body
     if (ids)
@@ -298,14 +354,18 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     if (nstatic > rounds) nstatic = rounds;
     if (nstatic < 1) nstatic = 1;
     if (dyn) flags |= kFlagDynamic;
-    if (use_pair)
+    if (use_win)
+      HIP_TRY(step_tables().window[e->d.n](e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
+                                           (uint32_t)e->first_id, flags, jarg, waves, e->ticket, e->ticket_base,
+                                           (int)nstatic, s));
+    else if (use_pair)
       HIP_TRY(step_tables().pair[e->d.n](e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
                                          (uint32_t)e->first_id, flags, jarg, waves, e->ticket, e->ticket_base,
                                          (int)nstatic, s));
     else
       HIP_TRY(step_for(e->d.n)(e->state, e->d.bpad, e->d.batch, actions, actions_out, status, seed,
                                (uint32_t)e->first_id, flags, jarg, e->waves, ids, nsub, rsteps, bpw, e->ticket,
-                               e->ticket_base, (int)nstatic, s));
+                               e->ticket_base, (int)nstatic, e->d.lay != 0, s));
     if (dyn) {
       // group g: its dynamic batches (idx >= nstatic * grid, idx % groups == g) + two draws per
       // wave that come back past the end (wraps with the counter)
@@ -410,6 +470,12 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->d.CH = twx::state_chunks(n);
   e->d.CHT = twx::total_chunks(n);
   e->d.ts = tile_shift(e->d.CHT);
+  // the big boards (whole-batch step = two lanes per board) live in the split layout and step through
+  // step_window_kernel; TWX_WINDOW=0 keeps them in the chunk layout on step_pair_kernel, TWX_PAIR=0 on the
+  // one-lane kernel (both for A/B runs and for the options only that kernel has: rolling compaction)
+  e->d.lay = (e->d.CHT > TWX_SMALL_CHT && env_int("TWX_WINDOW", 1, 0, 1) != 0 && env_int("TWX_PAIR", 1, 0, 1) != 0 &&
+              env_int("TWX_ROLLING", 0, 0, 1) == 0 && step_tables().wocc_j[n]() > 0 && step_tables().wocc_f[n]() > 0)
+                 ? 1 : 0;
   e->jpos = 0;
   e->period = env_int("TWX_JOURNAL_PERIOD", default_period(n), 1, twx::kJournalSlots);
   e->pingpong = env_int("TWX_PINGPONG", 1, 0, 1) != 0;
@@ -441,6 +507,11 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     const int pocc = step_tables().pocc[n]();
     e->pair = pocc > 0 && env_int("TWX_PAIR", 1, 0, 1) != 0;
     e->waves_pair = (cus > 0 ? cus : 256) * env_int("TWX_PAIR_WAVES_PER_CU", pocc > 0 ? pocc : 1, 1, 32);
+    e->waves_win = e->waves_win_full = 0;
+    if (e->d.lay) {
+      e->waves_win = (cus > 0 ? cus : 256) * env_int("TWX_WIN_WAVES_PER_CU", step_tables().wocc_j[n](), 1, 32);
+      e->waves_win_full = (cus > 0 ? cus : 256) * env_int("TWX_WIN_FULL_WAVES_PER_CU", step_tables().wocc_f[n](), 1, 32);
+    }
   }
   e->d.batch = batch;
   e->d.bpad = (batch + kWave - 1) / kWave * kWave;
@@ -448,7 +519,8 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   e->first_id = first_board_id;
   e->state = nullptr;
   e->tables = nullptr;
-  const size_t bytes = (size_t)e->d.CHT * (size_t)e->d.bpad * sizeof(uint4);
+  const size_t bytes = e->d.lay ? (size_t)(e->d.bpad / 32) * (size_t)split_tile_bytes(e->d.W)
+                                : (size_t)e->d.CHT * (size_t)e->d.bpad * sizeof(uint4);
   if (hipMalloc(&e->state, bytes) != hipSuccess) {
     delete e;
     return fail(TWX_E_NOMEM, "twx_create: hipMalloc of " + std::to_string(bytes) + " bytes failed");

@@ -24,7 +24,32 @@
 #endif
 constexpr int kAblate = TWX_ABLATE;
 
-template <int N, bool SUB>
+// SPLIT: the handle's state array is in the split layout (twixt_device_common.h; big boards whose
+// whole-batch step is step_window_kernel): this kernel then serves their listed-boards and play-out
+// launches only -- always on materialised planes, always rewriting its boards -- and gathers / scatters
+// a board's logical chunks piecewise (8-byte pieces) into the same LDS image.
+template <int W>
+__device__ __forceinline__ u32x4 split_load_chunk(const uint4 *state, long b, int c) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(state);
+  if (c >= 2 * W) return *reinterpret_cast<const u32x4 *>(w + split_scalar_index(0, b, W));
+  const int i = c >> 1;
+  const uint2 lo = *reinterpret_cast<const uint2 *>(w + split_word_index((c & 1) ? 4 : 0, i, b, W));
+  const uint2 hi = *reinterpret_cast<const uint2 *>(w + split_word_index((c & 1) ? 6 : 2, i, b, W));
+  return u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+template <int W>
+__device__ __forceinline__ void split_store_chunk(uint4 *state, long b, int c, uint4 v) {
+  uint32_t *w = reinterpret_cast<uint32_t *>(state);
+  if (c >= 2 * W) {
+    *reinterpret_cast<uint4 *>(w + split_scalar_index(0, b, W)) = v;
+    return;
+  }
+  const int i = c >> 1;
+  *reinterpret_cast<uint2 *>(w + split_word_index((c & 1) ? 4 : 0, i, b, W)) = make_uint2(v.x, v.y);
+  *reinterpret_cast<uint2 *>(w + split_word_index((c & 1) ? 6 : 2, i, b, W)) = make_uint2(v.z, v.w);
+}
+
+template <int N, bool SUB, bool SPLIT = false>
 __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, long batch,
                                                      const int32_t *__restrict__ actions,
                                                      int32_t *__restrict__ actions_out,
@@ -49,7 +74,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // the prefetched batch in AGPRs (big boards: one wave per SIMD owns all 512 registers)
   constexpr int TS = tile_shift(CHT);         // boards per tile of the state array: 64, or 32 for N >= 19
   constexpr int RB = 16 << TS;                // bytes of a chunk row of a tile
-  constexpr bool FAST = !SUB;
+  constexpr bool FAST = !SUB && !SPLIT;
   constexpr bool AG = FAST && CHT > TWX_SMALL_CHT;
   constexpr bool NT = CHT > TWX_PLAIN_STORE_CHT;  // non-temporal write-back where the board stream is the bound
   constexpr int NG = (CHT * RB + 8191) / 8192;  // per-lane offset registers: one per 8 KiB of a tile
@@ -144,7 +169,7 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   const int jslot = (lane & ((1 << TS) - 1)) >> (TS - 2);
   const bool load_j1 = rolling || jslot < jpos_arg, load_j2 = rolling || jslot < jpos_arg - 4;
   static_assert(twx::kJournalChunks == 2, "two journal rows");
-  constexpr int NL = SUB ? CJ : NJ;  // chunks a listed-boards launch moves
+  constexpr int NL = (SUB || SPLIT) ? CJ : NJ;  // chunks a listed-boards (or split-layout) launch moves
   if constexpr (FAST) {
     tile_load<0, CJ, AG, TS>(nxt, voff, tile_of(idx));
     if (load_j1) tile_load<CJ, CJ + 1, AG, TS>(nxt, voff, tile_of(idx));
@@ -154,7 +179,10 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
     long b0 = batch_board(idx);
     if (ids && (unsigned long)b0 >= (unsigned long)batch) b0 = 0;
 #pragma unroll
-    for (int j = 0; j < NL; j++) nxt[j] = gstate[chunk_index(j, b0, TS, CHT)];
+    for (int j = 0; j < NL; j++) {
+      if constexpr (SPLIT) nxt[j] = split_load_chunk<W>(state, b0, j);
+      else nxt[j] = gstate[chunk_index(j, b0, TS, CHT)];
+    }
 #pragma unroll
     for (int j = 0; j < NL; j++) asm volatile("" ::"v"(nxt[j]));  // first batch: nothing to overlap with
   }
@@ -230,7 +258,10 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       }
     } else {
 #pragma unroll
-      for (int j = c0; j < (c1 < NL ? c1 : NL); j++) nxt[j] = gstate[chunk_index(j, b1, TS, CHT)];
+      for (int j = c0; j < (c1 < NL ? c1 : NL); j++) {
+        if constexpr (SPLIT) nxt[j] = split_load_chunk<W>(state, b1, j);
+        else nxt[j] = gstate[chunk_index(j, b1, TS, CHT)];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -621,19 +652,21 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
   // ---- stream back ----
   // (LDS row j, slot lane holds chunk j of board bl: the fill's mapping)
   char *const tile_cur = tile_of(idx);
-  auto chunk_ptr = [&](int c) -> uint4 * {  // where chunk c of this lane's board lives
-    if constexpr (FAST)
-      return reinterpret_cast<uint4 *>(tile_cur + (lane_off + (uint32_t)c * (uint32_t)RB));
+  auto store_c = [&](int c, uint4 v) {  // chunk c of this lane's board
+    if constexpr (SPLIT)
+      split_store_chunk<W>(state, board, c, v);
+    else if constexpr (FAST)
+      tile_store<NT>(reinterpret_cast<uint4 *>(tile_cur + (lane_off + (uint32_t)c * (uint32_t)RB)), v);
     else
-      return state + chunk_index(c, board, TS, CHT);
+      tile_store<NT>(state + chunk_index(c, board, TS, CHT), v);
   };
   if (compact) {
     // planes and scalars from LDS.  The journal rows stay as they are (stale from now on); only
     // rolling compaction, where a reader cannot know a batch's position, clears them
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      if (wr && j < CJ) tile_store<NT>(chunk_ptr(j), lds4[j * kWave + lane]);
-      if (FAST && rolling && wr && j >= CJ) tile_store<NT>(chunk_ptr(j), make_uint4(0u, 0u, 0u, 0u));
+      if (wr && j < CJ) store_c(j, lds4[j * kWave + lane]);
+      if (FAST && rolling && wr && j >= CJ) store_c(j, make_uint4(0u, 0u, 0u, 0u));
     }
   } else {
     // this move's record: all a step normally writes -- one dword per board, a contiguous line per
@@ -652,14 +685,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       if (dd) {
         const int c = 2 * (__ffs((int)dd) - 1) + 1;  // chunk 2i+1 holds the flag words of group i
         dd &= dd - 1;
-        tile_store<NT>(chunk_ptr(c), lds4[c * BPW + bl]);
+        store_c(c, lds4[c * BPW + bl]);
       }
     }
     STAMP(10);  // dirty flag chunks
     if (__ballot(was_reset)) {  // auto-reset boards are rewritten whole
 #pragma unroll
       for (int j = 0; j < NJ; j++)
-        if (was_reset && j < CJ) tile_store<NT>(chunk_ptr(j), lds4[j * kWave + lane]);
+        if (was_reset && j < CJ) store_c(j, lds4[j * kWave + lane]);
     }
   }
   STAMP(11);  // reset lanes / compaction
@@ -687,14 +720,14 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
 
 // 64 boards per wave, big boards (N >= 19: listed-boards / play-out launches, and whole-batch steps
 // under TWX_PAIR=0): 39 KiB LDS image at N=24, 4 waves per CU, all 512 registers of the SIMD
-template <int N, bool SUB>
+template <int N, bool SUB, bool SPLIT = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) void step_kernel64(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, int rpw, uint32_t *__restrict__ ticket,
     TicketBases tbase, int nstatic) {
-  step_body<N, SUB>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                    rsteps, rpw, ticket, tbase, nstatic);
+  step_body<N, SUB, SPLIT>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                           rsteps, rpw, ticket, tbase, nstatic);
 }
 
 

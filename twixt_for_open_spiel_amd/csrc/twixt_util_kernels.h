@@ -11,6 +11,7 @@
 struct Dims {
   int n, W, SW, CH, CHT;  // CH: state chunks (planes + scalars); CHT: + the journal's chunk rows
   int ts;                 // tile_shift(CHT): boards per tile of the state array = 1 << ts
+  int lay;                // 0: chunk layout (tiles of [chunk][board]); 1: split layout (twixt_device_common.h)
   long batch, bpad;
 };
 
@@ -18,11 +19,42 @@ __device__ __forceinline__ uint32_t comp(const uint4 &v, int j) {
   return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
 }
 
-// word i of plane p / scalar j of board b in the interleaved internal layout
+// Logical chunk c of board b, whatever the handle's layout: c = 2i -> { red_i, blue_i, linkNNE_i,
+// linkENE_i }, c = 2i+1 -> { linkESE_i, linkSSE_i, start_i, end_i }, c = 2W -> the scalars.  In the
+// chunk layout that is one 16-byte load; in the split layout the pieces are 8-byte aligned.
+__device__ __forceinline__ uint4 load_chunk(const uint4 *state, const Dims &d, long b, int c) {
+  if (!d.lay) return state[chunk_index(c, b, d.ts, d.CHT)];
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(state);
+  if (c >= 2 * d.W) return *reinterpret_cast<const uint4 *>(w + split_scalar_index(0, b, d.W));
+  const int i = c >> 1;
+  const uint2 lo = *reinterpret_cast<const uint2 *>(w + ((c & 1) ? split_word_index(4, i, b, d.W) : split_word_index(0, i, b, d.W)));
+  const uint2 hi = *reinterpret_cast<const uint2 *>(w + ((c & 1) ? split_word_index(6, i, b, d.W) : split_word_index(2, i, b, d.W)));
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+// ... and the store; c in (2W, CHT) addresses the 16 bytes at board b's position of a journal row
+// (whole-batch reset only: together the boards of a tile cover the rows)
+__device__ __forceinline__ void store_chunk(uint4 *state, const Dims &d, long b, int c, uint4 v) {
+  if (!d.lay) {
+    state[chunk_index(c, b, d.ts, d.CHT)] = v;
+    return;
+  }
+  uint32_t *w = reinterpret_cast<uint32_t *>(state);
+  if (c >= 2 * d.W) {
+    *reinterpret_cast<uint4 *>(w + split_scalar_index(0, b, d.W) + (long)(c - 2 * d.W) * 128) = v;
+    return;
+  }
+  const int i = c >> 1;
+  *reinterpret_cast<uint2 *>(w + ((c & 1) ? split_word_index(4, i, b, d.W) : split_word_index(0, i, b, d.W))) = make_uint2(v.x, v.y);
+  *reinterpret_cast<uint2 *>(w + ((c & 1) ? split_word_index(6, i, b, d.W) : split_word_index(2, i, b, d.W))) = make_uint2(v.z, v.w);
+}
+
+// word i of plane p / scalar j of board b
 __device__ __forceinline__ uint32_t plane_word(const uint4 *state, const Dims &d, long b, int p, int i) {
+  if (d.lay) return reinterpret_cast<const uint32_t *>(state)[split_word_index(p, i, b, d.W)];
   return comp(state[chunk_index((2 * i + (p >> 2)), b, d.ts, d.CHT)], p & 3);
 }
 __device__ __forceinline__ uint32_t scalar_word(const uint4 *state, const Dims &d, long b, int j) {
+  if (d.lay) return reinterpret_cast<const uint32_t *>(state)[split_scalar_index(j, b, d.W)];
   return comp(state[chunk_index((2 * d.W), b, d.ts, d.CHT)], j);
 }
 
@@ -39,9 +71,9 @@ __global__ void reset_kernel(uint4 *state, Dims d, const uint32_t *init, const i
     b = ids[j];
     if (b < 0 || b >= d.batch) return;
   }
-  uint4 v;  // init is in internal chunk order; scalars and journal rows are zero
+  uint4 v;  // init is in logical chunk order; scalars and journal rows are zero
   v.x = init[4 * c + 0]; v.y = init[4 * c + 1]; v.z = init[4 * c + 2]; v.w = init[4 * c + 3];
-  state[chunk_index(c, b, d.ts, d.CHT)] = v;
+  store_chunk(state, d, b, c, v);
 }
 
 // canonical (include/twixt_hip.h) order out: one thread per (board, word)
@@ -74,7 +106,7 @@ __global__ void import_kernel(uint4 *state, Dims d, const int32_t *ids, long n, 
     const uint32_t *sc = src + twx::kNumPlanes * d.W;
     v.x = sc[0]; v.y = sc[1] & ~(15u << twx::kJBaseShift); v.z = sc[2]; v.w = sc[3];  // (journal base: an internal field)
   }
-  state[chunk_index(c, b, d.ts, d.CHT)] = v;
+  store_chunk(state, d, b, c, v);
 }
 
 __global__ void copy_kernel(uint4 *dst, Dims dd, const int32_t *dst_ids, const uint4 *src, Dims sd,
@@ -85,7 +117,7 @@ __global__ void copy_kernel(uint4 *dst, Dims dd, const int32_t *dst_ids, const u
   if (c >= dd.CH) return;
   const long db = dst_ids[j], sb = src_ids[j];
   if (db < 0 || db >= dd.batch || sb < 0 || sb >= sd.batch) return;
-  dst[chunk_index(c, db, dd.ts, dd.CHT)] = src[chunk_index(c, sb, sd.ts, sd.CHT)];
+  store_chunk(dst, dd, db, c, load_chunk(src, sd, sb, c));
 }
 
 // tw.h:86-90 as a mask: one thread per (board, mask word)
@@ -119,7 +151,7 @@ __global__ void status_kernel(const uint4 *state, Dims d, int jpos, const int32_
   if (j >= n) return;
   const long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) return;
-  const uint4 s = state[chunk_index((d.CH - 1), b, d.ts, d.CHT)];
+  const uint4 s = load_chunk(state, d, b, d.CH - 1);
   uint32_t counter = s.x & 0xffffu, res = s.y & 0xffu, move_one = s.x >> 16, swapped = (s.y >> 8) & 1u;
   // the stored scalars are as old as the planes: advance them by the board's journal records
   // ([slot][board] rows) from the board's base slot up to the handle's journal position (the
@@ -127,7 +159,8 @@ __global__ void status_kernel(const uint4 *state, Dims d, int jpos, const int32_
   const uint32_t *const words = reinterpret_cast<const uint32_t *>(state);
   const int jbase = (int)((s.y >> twx::kJBaseShift) & 15u);
   for (int sl = jbase; sl < jpos; sl++)
-    twx::journal_scalars(words[journal_word_index(sl, b, d.ts, d.CHT)], counter, move_one, res, swapped);
+    twx::journal_scalars(words[d.lay ? split_journal_index(sl, b, d.W) : journal_word_index(sl, b, d.ts, d.CHT)], counter,
+                         move_one, res, swapped);
   if (result) result[j] = (uint8_t)res;
   if (move_counter) move_counter[j] = (int32_t)counter;
   if (current_player) current_player[j] = res ? (int8_t)-4 : (int8_t)(counter & 1u);  // tw.h:99-103
@@ -200,7 +233,7 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
   const long j = blockIdx.x;  // output row
   long b = ids ? ids[j] : j;
   if (b < 0 || b >= d.batch) b = 0;  // host validated; keep the block's barriers uniform
-  for (int c = lane; c < 2 * W + 1; c += kWave) sst[c] = state[chunk_index(c, b, d.ts, d.CHT)];
+  for (int c = lane; c < 2 * W + 1; c += kWave) sst[c] = load_chunk(state, d, b, c);
   for (int i = lane; i < npos; i += kWave) { feat[0][i] = 0; feat[1][i] = 0; }
   __syncthreads();
   const uint32_t *w = reinterpret_cast<const uint32_t *>(sst);
