@@ -128,6 +128,10 @@ int pair_occupancy() {
 typedef hipError_t (*pair_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t, int, int,
                               int, uint32_t *, TicketBases, int, hipStream_t);
 
+inline int env_int_early(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 // windowed step on the split layout (twixt_window_kernel.h): whole-batch steps of the big boards; the
 // launches that rewrite everything (compactions, flushes) run the FULL instantiation
 template <int N>
@@ -138,11 +142,18 @@ hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *act
     const long nbatch = bpad / 32;
     const long grid = nbatch < (long)waves ? nbatch : (long)waves;
     const bool full = (flags & kFlagCompact) != 0;
+#ifdef TWX_DIAG_NOFLOOD
+    if (env_int_early("TWX_DIAG_NOFLOOD", 0)) flags |= 1 << 28;
+#endif
     const size_t lds_bytes = (size_t)WinGeo<N>::lds_bytes(full);
     char *st = reinterpret_cast<char *>(state);
+    static const bool pipe = env_int_early("TWX_WIN_PIPE", 1) != 0;
     if (full)
       hipLaunchKernelGGL((step_window_full_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
                          actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
+    else if (!pipe)
+      hipLaunchKernelGGL((step_window_kernel3<N>), dim3((unsigned)grid), dim3(kWave), (size_t)WinGeo<N>::lds_bytes3(), s, st, bpad,
+                         batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
     else
       hipLaunchKernelGGL((step_window_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
                          actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
