@@ -171,14 +171,21 @@ __device__ __forceinline__ void tile_store_word(uint32_t *p, uint32_t v) {
 // v_accvgpr_* in the kernel).  Untracked younger loads only make the compiler's own counted
 // waits stricter, never weaker (vmcnt counts in order).
 // ---------------------------------------------------------------------------
+// HAZARD (gfx9 / CDNA): a VMEM instruction must not read an SGPR within 5 wait states of a VALU instruction that
+// wrote it (v_readlane_b32 / v_readfirstlane_b32: the compiler's SGPR spill reloads, uniform_ptr()).  The
+// compiler pads its own instructions with s_nop, but it does not look into inline asm -- with the tile
+// pointer reloaded from a spill lane right before an asm load, the load used a stale base and faulted
+// (round 3: step_window1_kernel<22>, "Memory access fault ... 0xffff..."; whether it bites depends on the
+// register allocation).  So every asm load with a scalar base carries its own wait states.
+#define TWX_SGPR_HAZARD_NOP "s_nop 4\n\t"
 template <int J, bool AG, int TS>
 __device__ __forceinline__ void tile_load_chunk(u32x4 &dst, uint32_t voff, const void *tile) {
   constexpr int RB = 16 << TS, CPO = 8192 / RB;
   if constexpr (AG)
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
+    asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
                  "n"((J % CPO) * RB - 4096) : "memory");
   else
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(tile),
+    asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(tile),
                  "n"((J % CPO) * RB - 4096) : "memory");
 }
 template <int C0, int C1, bool AG, int TS>
@@ -205,7 +212,7 @@ __device__ __forceinline__ void tile_fill(uint32_t lds_lane, const u32x4 *nxt) {
 // KiB; one register reaches eight pairs (8 KiB); always AGPRs.  LDS image rows are 512 B too.
 template <int J>
 __device__ __forceinline__ void pair_tile_load_chunk(u32x4 &dst, uint32_t voff, const void *tile) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
+  asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(tile),
                "n"((J % 8) * 1024 - 4096) : "memory");
 }
 template <int C0, int C1>

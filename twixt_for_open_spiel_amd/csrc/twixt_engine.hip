@@ -62,6 +62,7 @@ int fail(int code, const std::string &msg) {
 #include "twixt_step_kernel.h"
 #include "twixt_pair_kernel.h"
 #include "twixt_window_kernel.h"
+#include "twixt_window1_kernel.h"
 #include "twixt_util_kernels.h"
 
 template <int N>
@@ -148,6 +149,14 @@ hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *act
     const size_t lds_bytes = (size_t)WinGeo<N>::lds_bytes(full);
     char *st = reinterpret_cast<char *>(state);
     static const bool pipe = env_int_early("TWX_WIN_PIPE", 1) != 0;
+    static const int lanes = env_int_early("TWX_WIN_LANES", 1);  // journal launches: 1 lane per board (64 per wave) or 2
+    if (!full && lanes == 1) {
+      const long nb64 = bpad / 64;
+      const long grid1 = nb64 < (long)waves ? nb64 : (long)waves;
+      hipLaunchKernelGGL((step_window1_kernel<N>), dim3((unsigned)grid1), dim3(kWave), (size_t)Win1Geo<N>::lds_bytes, s, st, bpad,
+                         batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
+      return hipGetLastError();
+    }
     if (full)
       hipLaunchKernelGGL((step_window_full_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
                          actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
@@ -173,6 +182,16 @@ int window_occupancy_j() {
   return 0;
 }
 template <int N>
+int window_occupancy_1() {
+  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window1_kernel<N>, kWave, (size_t)Win1Geo<N>::lds_bytes) != hipSuccess)
+      return 0;
+    return blocks;
+  }
+  return 0;
+}
+template <int N>
 int window_occupancy_f() {
   if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
     int blocks = 0;
@@ -189,7 +208,7 @@ typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, u
 
 template <int N>
 struct StepTable {
-  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po, pair_fn *w, occ_fn *wj, occ_fn *wf) {
+  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po, pair_fn *w, occ_fn *wj, occ_fn *wf, occ_fn *w1) {
     t[N] = &launch_step<N>;
     o[N] = &step_occupancy<N>;
     p[N] = &launch_pair<N>;
@@ -197,12 +216,13 @@ struct StepTable {
     w[N] = &launch_window<N>;
     wj[N] = &window_occupancy_j<N>;
     wf[N] = &window_occupancy_f<N>;
-    StepTable<N - 1>::fill(t, o, p, po, w, wj, wf);
+    w1[N] = &window_occupancy_1<N>;
+    StepTable<N - 1>::fill(t, o, p, po, w, wj, wf, w1);
   }
 };
 template <>
 struct StepTable<TWX_MIN_BOARD_SIZE - 1> {
-  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *, pair_fn *, occ_fn *, occ_fn *) {}
+  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *, pair_fn *, occ_fn *, occ_fn *, occ_fn *) {}
 };
 
 struct StepTables {
@@ -211,8 +231,8 @@ struct StepTables {
   pair_fn pair[TWX_MAX_BOARD_SIZE + 1];
   occ_fn pocc[TWX_MAX_BOARD_SIZE + 1];
   pair_fn window[TWX_MAX_BOARD_SIZE + 1];
-  occ_fn wocc_j[TWX_MAX_BOARD_SIZE + 1], wocc_f[TWX_MAX_BOARD_SIZE + 1];
-  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc, window, wocc_j, wocc_f); }
+  occ_fn wocc_j[TWX_MAX_BOARD_SIZE + 1], wocc_f[TWX_MAX_BOARD_SIZE + 1], wocc_1[TWX_MAX_BOARD_SIZE + 1];
+  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc, window, wocc_j, wocc_f, wocc_1); }
 };
 const StepTables &step_tables() {
   static const StepTables t;  // thread-safe static init
@@ -245,6 +265,7 @@ struct twx_env {
   // split layout (d.lay = 1): whole-batch launches go to step_window_kernel; persistent grids of its journal
   // and of its rewriting instantiation
   int waves_win, waves_win_full;
+  bool win_one_lane;  // journal launches: step_window1_kernel (one lane per board, 64 boards per wave)
   int cus;         // compute units of the device
   // dynamic batch order (TWX_DYNAMIC): device ticket counters (never reset) and the values
   // they will have when the next launch starts
@@ -339,7 +360,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     // whole-batch launches of the big boards: the two-lanes-per-board kernel
     const bool use_win = e->d.lay != 0 && !ids && rsteps == 1;
     const bool use_pair = use_win || (e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling));
-    int bpw = use_pair ? 32 : kWave;  // boards per wave
+    int bpw = (use_pair && !(use_win && e->win_one_lane && !(flags & kFlagCompact))) ? 32 : kWave;  // boards per wave
     const int waves = use_win ? ((flags & kFlagCompact) ? e->waves_win_full : e->waves_win) : use_pair ? e->waves_pair : e->waves;
     // a short list of boards is spread over many waves (rows per wave: a power of two, at least 4,
     // while that still fills four waves per CU): see step_body
@@ -519,8 +540,11 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     e->pair = pocc > 0 && env_int("TWX_PAIR", 1, 0, 1) != 0;
     e->waves_pair = (cus > 0 ? cus : 256) * env_int("TWX_PAIR_WAVES_PER_CU", pocc > 0 ? pocc : 1, 1, 32);
     e->waves_win = e->waves_win_full = 0;
+    e->win_one_lane = false;
     if (e->d.lay) {
-      e->waves_win = (cus > 0 ? cus : 256) * env_int("TWX_WIN_WAVES_PER_CU", step_tables().wocc_j[n](), 1, 32);
+      e->win_one_lane = env_int("TWX_WIN_LANES", 1, 1, 2) == 1 && step_tables().wocc_1[n]() > 0;
+      e->waves_win = (cus > 0 ? cus : 256) *
+                     env_int("TWX_WIN_WAVES_PER_CU", e->win_one_lane ? step_tables().wocc_1[n]() : step_tables().wocc_j[n](), 1, 32);
       e->waves_win_full = (cus > 0 ? cus : 256) * env_int("TWX_WIN_FULL_WAVES_PER_CU", step_tables().wocc_f[n](), 1, 32);
     }
   }

@@ -77,18 +77,18 @@ struct WinGeo {
 // 16 bytes: global -> AGPRs / AGPRs -> LDS (twixt_device_common.h "Tile I/O": the compiler does not see
 // these loads; the kernel waits for them explicitly)
 __device__ __forceinline__ void gload16(u32x4 &dst, uint32_t voff, const void *base) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(dst) : "v"(voff), "s"(base) : "memory");
+  asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2" : "=a"(dst) : "v"(voff), "s"(base) : "memory");
 }
 template <int IMM>
 __device__ __forceinline__ void gload16i(u32x4 &dst, uint32_t voff, const void *base) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+  asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 __device__ __forceinline__ void lwrite16(uint32_t lds_addr, const u32x4 &v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(v) : "memory");
 }
 // (the same through VGPRs: the short-lived window / flood pieces)
 __device__ __forceinline__ void gload16v(u32x4 &dst, uint32_t voff, const void *base) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+  asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
 }
 __device__ __forceinline__ void lwrite16v(uint32_t lds_addr, const u32x4 &v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
@@ -99,7 +99,7 @@ __device__ __forceinline__ void gload16p(u32x4 &dst, const void *addr) {
 }
 template <int IMM>
 __device__ __forceinline__ void gload16iv(u32x4 &dst, uint32_t voff, const void *base) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+  asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 template <int IMM>
 __device__ __forceinline__ void lwrite16iv(uint32_t lds_addr, const u32x4 &v) {
