@@ -47,12 +47,48 @@ def algo_bytes(n):
     return ALGO_BYTES.get(n, 2 * (9 * ((n * n + 7) // 8) + 8) + 8)
 
 
+def split_layout(n):
+    """Big boards (N >= 19, TWX_SMALL_CHT): split layout, windowed step (twixt_window1_kernel.h)."""
+    return 2 * ((n * n + 31) // 32) + 3 > 25
+
+
 def step_kernel_name(n):
-    """The kernel a whole-batch step launch runs at board size n (twixt_engine.hip run_step)."""
-    cht = 2 * ((n * n + 31) // 32) + 3
-    if cht > 25:   # TWX_SMALL_CHT: N >= 19
-        return "step_pair_kernel<%d>" % n
+    """The kernel most whole-batch step launches run at board size n (twixt_engine.hip run_step):
+    the journal launches of the big boards; their compactions run compaction_kernel_name(n)."""
+    if split_layout(n):
+        return "step_window1_kernel<%d>" % n
     return "step_kernel64_small<%d, false>" % n
+
+
+def compaction_kernel_name(n):
+    return "step_window_full_kernel<%d>" % n if split_layout(n) else step_kernel_name(n)
+
+
+def window_geometry(n):
+    """WinGeo<N> of twixt_window_kernel.h: words per plane, peg rows, bytes of a board's links + flags
+    region, words and 16-byte pieces of a move's window."""
+    w = (n * n + 31) // 32
+    rp = (w + 1) // 2
+    lfb = (24 * w + 15) // 16 * 16
+    nw = min((6 * n + 62) // 32, w)
+    npc = min((24 * nw + 8 + 15) // 16, lfb // 16)
+    return {"W": w, "RP": rp, "LFB": lfb, "NW": nw, "NPC": npc}
+
+
+def design_bytes_split(n, multi_cell_fills=0.028):
+    """Bytes the windowed step requests per env step by construction, big boards.
+    Journal launch with j records: pegs (8 W) + scalars (16) + the records (4 j) + the window (16 NPC) +
+    the whole region of the boards with a multi-cell fill; it writes its record (4 B).  The compaction
+    reads the whole tile (pegs, scalars, P-1 records, regions) and writes pegs, scalars and regions.
+    Returns (per step averaged over a period, journal launch mean, compaction launch).  The memory side
+    moves whole 128-byte lines: a window of 160 B at a 16-byte offset touches 2.1 of them on average, so the
+    PMC traffic of a journal launch is above this request count."""
+    g, p = window_geometry(n), journal_period(n)
+    rows = 8 * g["W"] + 16
+    journal = [rows + 4 * j + 16 * g["NPC"] + multi_cell_fills * g["LFB"] + 4 for j in range(p - 1)]
+    compaction = (rows + 4 * (p - 1) + g["LFB"]) + (rows + g["LFB"])
+    jmean = sum(journal) / max(1, len(journal))
+    return (sum(journal) + compaction) / p, jmean, compaction
 
 
 def design_bytes(n):
@@ -62,6 +98,8 @@ def design_bytes(n):
     period fetches j of them); P-1 launches in P write one journal record (4 B: it carries the
     scalars), the P-th rewrites the CH chunks.  (Flag chunks a multi-cell flood fill dirtied,
     auto-reset boards, and the 5 B of actions + status a step reports add a few bytes.)"""
+    if split_layout(n):
+        return design_bytes_split(n)[0]
     ch = 2 * ((n * n + 31) // 32) + 1
     p = journal_period(n)
     return 16.0 * ch + 4.0 * sum(range(p)) / p + ((p - 1) * 4.0 + 16.0 * ch) / p
@@ -147,6 +185,7 @@ def measured_traffic(n, batch):
         src["rejected"] = "measured on another build of libtwixt_hip.so (library hash differs; sources %s)" % (
             "match" if js.get("source_stamp") == src["source_stamp_now"] else "differ too")
     else:
+        src["per_kernel"] = js.get("per_kernel")
         return float(js["hbm_bytes_per_launch"]), src
     return None, src
 
@@ -214,6 +253,25 @@ def small_batch_latency(device, seed, cases=((12, 2048), (24, 16384)), steps=300
         out.append({"board_size": n, "batch": b, "us_per_step": us, "env_steps_per_s": b / (us * 1e-6)})
         env.close()
     return out
+
+
+def per_kernel_launch_ms(launch, sync, period, launches_so_far, periods=8):
+    """HIP-event time of every launch over `periods` journal periods, split into the journal launches and
+    the compactions (every period-th whole-batch step since the handle was created).  Separate from the
+    timed region: an event per launch would perturb it."""
+    import torch
+    k = period * periods
+    sync()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+    ev[0].record()
+    for i in range(k):
+        launch()
+        ev[i + 1].record()
+    sync()
+    t = [ev[i].elapsed_time(ev[i + 1]) for i in range(k)]
+    comp = [t[i] for i in range(k) if (launches_so_far + i) % period == period - 1]
+    jour = [t[i] for i in range(k) if (launches_so_far + i) % period != period - 1]
+    return (sum(jour) / len(jour) if jour else None), (sum(comp) / len(comp) if comp else None)
 
 
 def shard_first_board(rank, batch_per_gpu):
@@ -400,6 +458,10 @@ def main(argv=None):
     barrier()
     kernel_ms = kernel_ms_sum / (K * blocks) if env is not None else elapsed * 1e3 / (K * blocks)
 
+    journal_ms = compaction_ms = None
+    if env is not None and rank == 0 and journal_period(n) > 1 and not active_knobs():
+        done = args.prologue + args.warmup + K * blocks
+        journal_ms, compaction_ms = per_kernel_launch_ms(launch, sync, journal_period(n), done)
     hist = None
     if env is not None:
         res, _, _ = env.status()
@@ -415,8 +477,20 @@ def main(argv=None):
         agg = aggregate(per_rank, B, K, blocks)
         ab, db = algo_bytes(n), design_bytes(n)
         traffic, traffic_src = (None, {"rejected": "dry run"}) if args.dry_run else measured_traffic(n, B)
-        moved = traffic if traffic is not None else db * B  # bytes per launch the roofline is priced on
-        achieved = moved / (kernel_ms * 1e-3) / 1e9
+        moved = traffic if traffic is not None else db * B  # bytes per launch (mean over a period) really moved
+        achieved_all = moved / (kernel_ms * 1e-3) / 1e9
+        # the dominant kernel: the journal launches (P-1 of P); its own bytes and its own launch time
+        pk = (traffic_src or {}).get("per_kernel") or {}
+        dom, comp_name = step_kernel_name(n), compaction_kernel_name(n)
+        if journal_ms is not None and split_layout(n):
+            dom_bytes = pk.get(dom, {}).get("hbm_bytes_per_launch") if traffic is not None else None
+            dom_traffic = dom_bytes
+            if dom_bytes is None:
+                dom_bytes = design_bytes_split(n)[1] * B
+            dom_ms = journal_ms
+        else:
+            dom_bytes, dom_traffic, dom_ms = moved, traffic, kernel_ms
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         out = {
             "metric": "env steps/sec at board_size=%d, batch=%d per GPU, random-action rollouts" % (n, B),
             "value": agg["value"],
@@ -443,19 +517,29 @@ def main(argv=None):
                                  "value = all env steps / slowest rank's summed block time" % (blocks, K),
                        "result_hist_rank0": hist, "dry_run": bool(args.dry_run)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "basis": ("bytes moved per launch by PMC (traffic) / kernel time" if traffic is not None else
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": dom_traffic,
+                         "basis": ("bytes moved per launch of this kernel by PMC (traffic) / its mean launch time" if dom_traffic is not None else
                                    "design byte model x boards / kernel time (no PMC measurement of this build and "
                                    "workload is committed: traffic is null)"),
                          "traffic_source": traffic_src,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                         "kernel": step_kernel_name(n),
-                         "kernel_ms": kernel_ms,
+                         "kernel": dom,
+                         "kernel_ms": dom_ms,
+                         "share_of_launches": (journal_period(n) - 1.0) / journal_period(n) if split_layout(n) else 1.0,
+                         "all_launches": {"kernels": [dom, comp_name] if split_layout(n) else [dom],
+                                          "mean_launch_ms": kernel_ms, "hbm_bytes_per_launch_mean": moved,
+                                          "achieved_GBps": achieved_all, "frac": achieved_all / HBM_PEAK_GBS,
+                                          "note": "HIP events over the timed region, journal launches and compactions alike"},
+                         "compaction": ({"kernel": comp_name, "kernel_ms": compaction_ms,
+                                         "traffic": pk.get(comp_name, {}).get("hbm_bytes_per_launch") if traffic is not None else None,
+                                         "model_bytes_per_launch": design_bytes_split(n)[2] * B}
+                                        if split_layout(n) and compaction_ms is not None else None),
                          "design_model_bytes_per_env_step": db,
                          "traffic_over_design_model": (traffic / B / db) if traffic is not None else None,
+                         "journal_launch_model_bytes_per_board": design_bytes_split(n)[1] if split_layout(n) else None,
                          "algorithmic_bytes_per_env_step": ab,
-                         "algorithmic_equivalent_GBps": ab * B / (kernel_ms * 1e-3) / 1e9,
+                         "algorithmic_equivalent_GBps": ab * B / (kernel_ms * 1e-3) / 1e9,  # (over all launches)
                          "note": "frac = bytes really moved / kernel time / 8 TB/s, so it cannot exceed 1.  "
                                  "algorithmic_equivalent_GBps prices the same launches at SURVEY 8(d)'s %d B per env "
                                  "step (full state read + write); the log-structured state moves fewer bytes than "

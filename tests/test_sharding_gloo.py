@@ -133,11 +133,18 @@ def test_roofline_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
 
 def test_design_byte_model():
     import bench
-    # N=24, period 8: 37 chunks read + the period's records so far (0..7 of 4 B); 7 records + one rewrite written
-    assert bench.design_bytes(24) == 592 + 4 * 28 / 8 + (7 * 4 + 592) / 8 == 683.5
+    # N=24 (split layout, windowed step), period 8: a journal launch with j records requests pegs + scalars
+    # (160 B), the records (4 j), the window (10 pieces of 16 B), 2.8 % of a whole region (432 B) for the
+    # multi-cell fills, and writes its record; the compaction reads the whole tile and writes pegs, scalars, region
+    per_step, journal, compaction = bench.design_bytes_split(24)
+    assert abs(journal - (160 + 4 * 3 + 160 + 0.028 * 432 + 4)) < 1e-9 and compaction == (160 + 28 + 432) + (160 + 432)
+    assert abs(per_step - (7 * journal + compaction) / 8) < 1e-9 and bench.design_bytes(24) == per_step
+    assert bench.window_geometry(24) == {"W": 18, "RP": 9, "LFB": 432, "NW": 6, "NPC": 10}
+    assert bench.window_geometry(19)["NPC"] == 8 and bench.window_geometry(20)["LFB"] == 320
     assert bench.design_bytes(8) == 2 * 80 and bench.journal_period(9) == 1        # no journal: read + write the board
     assert [bench.journal_period(n) for n in (10, 12, 13, 17, 18, 24)] == [2, 2, 4, 4, 8, 8]
-    assert bench.step_kernel_name(24) == "step_pair_kernel<24>" and "small" in bench.step_kernel_name(12)
+    assert bench.step_kernel_name(24) == "step_window1_kernel<24>" and "small" in bench.step_kernel_name(12)
+    assert bench.compaction_kernel_name(24) == "step_window_full_kernel<24>"
     assert bench.algo_bytes(24) == 1320 and bench.algo_bytes(12) == 348 and bench.algo_bytes(8) == 168
 
 

@@ -11,7 +11,7 @@ import sys
 
 out_path, dirs = sys.argv[1], sys.argv[2:]
 tag, k = os.environ.get("PMC_KERNEL", ""), 64
-TAGS = [tag] if tag else ["step_pair_kernel<24>", "step_kernel64<24, false>"]
+TAGS = [tag] if tag else ["step_window1_kernel<24>", "step_pair_kernel<24>", "step_kernel64<24, false>"]
 res = {}
 for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

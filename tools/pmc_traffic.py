@@ -35,13 +35,30 @@ def main():
     k = int(sys.argv[4]) if len(sys.argv) > 4 else 64
     n = int(sys.argv[5]) if len(sys.argv) > 5 else 24
     b = int(sys.argv[6]) if len(sys.argv) > 6 else 1 << 20
-    # whichever whole-batch step kernel the library runs at this board size
-    tags = ["step_pair_kernel<%d>" % n, "step_kernel64<%d, false>" % n, "step_kernel64_small<%d, false>" % n]
-    tag = os.environ.get("PMC_KERNEL") or next(
-        (t for t in tags if per_dispatch(fetch_dir, "FETCH_SIZE", t)), tags[0])
-    out = {}
+    # whichever whole-batch step kernels the library runs at this board size: the big boards' journal
+    # launches and compactions are two kernels (step_window1_kernel / step_window_full_kernel); the tag
+    # "step_" + "<N" catches every whole-batch step kernel of the size, in launch order
+    tags = ["step_window1_kernel<%d>" % n, "step_window_full_kernel<%d>" % n, "step_window_kernel<%d>" % n,
+            "step_pair_kernel<%d>" % n, "step_kernel64<%d, false>" % n, "step_kernel64_small<%d, false>" % n]
+    present = [t for t in tags if per_dispatch(fetch_dir, "FETCH_SIZE", t)]
+    if os.environ.get("PMC_KERNEL"):
+        present = [os.environ["PMC_KERNEL"]]
+    tag = present[0] if present else tags[0]
+
+    def rows_of(directory, name):  # the timed launches of all step kernels, in dispatch order
+        rows = []
+        for t in present:
+            rows += [(d, v, t) for d, v in per_dispatch(directory, name, t)]
+        return sorted(rows)[-k:]
+    out, per_kernel = {}, {}
     for name, directory in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
-        rows = per_dispatch(directory, name, tag)[-k:]  # the timed launches come last
+        rows3 = rows_of(directory, name)
+        rows = [(d, v) for d, v, _ in rows3]
+        for t in present:
+            vals = [v for _, v, tt in rows3 if tt == t]
+            if vals:
+                per_kernel.setdefault(t, {})[name] = sum(vals) / len(vals)
+                per_kernel[t]["launches"] = len(vals)
         if len(rows) < k:
             raise SystemExit("%s: only %d launches of %s" % (name, len(rows), tag))
         with open("%s_pmc_%s.csv" % (prefix, name.split("_")[0].lower()), "w") as fh:
@@ -60,6 +77,12 @@ def main():
         "FETCH_SIZE_KB_per_launch_mean": out["FETCH_SIZE"],
         "WRITE_SIZE_KB_per_launch_mean": out["WRITE_SIZE"],
         "kernel": tag,
+        # per kernel: mean bytes of ITS launches (FETCH_SIZE doubled as above)
+        "per_kernel": {t: {"launches": v.get("launches"),
+                           "fetch_bytes_corrected_per_launch": 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0,
+                           "write_bytes_per_launch": v.get("WRITE_SIZE", 0.0) * 1024.0,
+                           "hbm_bytes_per_launch": 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0 + v.get("WRITE_SIZE", 0.0) * 1024.0}
+                       for t, v in per_kernel.items()},
         "workload": "bench.py --steps %d --warmup 0 (N=%d, B=%d): last %d launches" % (k, n, b, k),
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
                   "(MI355X_MICROARCH.md HBM section); FETCH_SIZE doubled: on gfx950 it reports 1/2 of the "

@@ -129,10 +129,6 @@ int pair_occupancy() {
 typedef hipError_t (*pair_fn)(uint4 *, long, long, const int32_t *, int32_t *, uint8_t *, uint32_t, uint32_t, int, int,
                               int, uint32_t *, TicketBases, int, hipStream_t);
 
-inline int env_int_early(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 // windowed step on the split layout (twixt_window_kernel.h): whole-batch steps of the big boards; the
 // launches that rewrite everything (compactions, flushes) run the FULL instantiation
 template <int N>
@@ -143,44 +139,22 @@ hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *act
     const long nbatch = bpad / 32;
     const long grid = nbatch < (long)waves ? nbatch : (long)waves;
     const bool full = (flags & kFlagCompact) != 0;
-#ifdef TWX_DIAG_NOFLOOD
-    if (env_int_early("TWX_DIAG_NOFLOOD", 0)) flags |= 1 << 28;
-#endif
-    const size_t lds_bytes = (size_t)WinGeo<N>::lds_bytes(full);
+    const size_t lds_bytes = (size_t)WinGeo<N>::lds_bytes_full;
     char *st = reinterpret_cast<char *>(state);
-    static const bool pipe = env_int_early("TWX_WIN_PIPE", 1) != 0;
-    static const int lanes = env_int_early("TWX_WIN_LANES", 1);  // journal launches: 1 lane per board (64 per wave) or 2
-    if (!full && lanes == 1) {
+    if (!full) {  // journal launches: one lane per board, 64 boards per wave (twixt_window1_kernel.h)
       const long nb64 = bpad / 64;
       const long grid1 = nb64 < (long)waves ? nb64 : (long)waves;
       hipLaunchKernelGGL((step_window1_kernel<N>), dim3((unsigned)grid1), dim3(kWave), (size_t)Win1Geo<N>::lds_bytes, s, st, bpad,
                          batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
-      return hipGetLastError();
-    }
-    if (full)
+    } else {  // compactions, flushes: two lanes per board, whole tiles (twixt_window_kernel.h)
       hipLaunchKernelGGL((step_window_full_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
                          actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
-    else if (!pipe)
-      hipLaunchKernelGGL((step_window_kernel3<N>), dim3((unsigned)grid), dim3(kWave), (size_t)WinGeo<N>::lds_bytes3(), s, st, bpad,
-                         batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
-    else
-      hipLaunchKernelGGL((step_window_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
-                         actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
+    }
     return hipGetLastError();
   }
   return hipErrorInvalidConfiguration;
 }
 // resident waves per CU of the journal (0) / the rewriting (1) instantiation
-template <int N>
-int window_occupancy_j() {
-  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
-    int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_kernel<N>, kWave, (size_t)WinGeo<N>::lds_bytes(false)) != hipSuccess)
-      return 0;
-    return blocks;
-  }
-  return 0;
-}
 template <int N>
 int window_occupancy_1() {
   if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
@@ -195,7 +169,7 @@ template <int N>
 int window_occupancy_f() {
   if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_full_kernel<N>, kWave, (size_t)WinGeo<N>::lds_bytes(true)) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_full_kernel<N>, kWave, (size_t)WinGeo<N>::lds_bytes_full) != hipSuccess)
       return 0;
     return blocks;
   }
@@ -208,21 +182,20 @@ typedef hipError_t (*step_fn)(uint4 *, long, long, const int32_t *, int32_t *, u
 
 template <int N>
 struct StepTable {
-  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po, pair_fn *w, occ_fn *wj, occ_fn *wf, occ_fn *w1) {
+  static void fill(step_fn *t, occ_fn *o, pair_fn *p, occ_fn *po, pair_fn *w, occ_fn *wf, occ_fn *w1) {
     t[N] = &launch_step<N>;
     o[N] = &step_occupancy<N>;
     p[N] = &launch_pair<N>;
     po[N] = &pair_occupancy<N>;
     w[N] = &launch_window<N>;
-    wj[N] = &window_occupancy_j<N>;
     wf[N] = &window_occupancy_f<N>;
     w1[N] = &window_occupancy_1<N>;
-    StepTable<N - 1>::fill(t, o, p, po, w, wj, wf, w1);
+    StepTable<N - 1>::fill(t, o, p, po, w, wf, w1);
   }
 };
 template <>
 struct StepTable<TWX_MIN_BOARD_SIZE - 1> {
-  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *, pair_fn *, occ_fn *, occ_fn *, occ_fn *) {}
+  static void fill(step_fn *, occ_fn *, pair_fn *, occ_fn *, pair_fn *, occ_fn *, occ_fn *) {}
 };
 
 struct StepTables {
@@ -231,8 +204,8 @@ struct StepTables {
   pair_fn pair[TWX_MAX_BOARD_SIZE + 1];
   occ_fn pocc[TWX_MAX_BOARD_SIZE + 1];
   pair_fn window[TWX_MAX_BOARD_SIZE + 1];
-  occ_fn wocc_j[TWX_MAX_BOARD_SIZE + 1], wocc_f[TWX_MAX_BOARD_SIZE + 1], wocc_1[TWX_MAX_BOARD_SIZE + 1];
-  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc, window, wocc_j, wocc_f, wocc_1); }
+  occ_fn wocc_f[TWX_MAX_BOARD_SIZE + 1], wocc_1[TWX_MAX_BOARD_SIZE + 1];
+  StepTables() { StepTable<TWX_MAX_BOARD_SIZE>::fill(step, occ, pair, pocc, window, wocc_f, wocc_1); }
 };
 const StepTables &step_tables() {
   static const StepTables t;  // thread-safe static init
@@ -506,7 +479,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   // step_window_kernel; TWX_WINDOW=0 keeps them in the chunk layout on step_pair_kernel, TWX_PAIR=0 on the
   // one-lane kernel (both for A/B runs and for the options only that kernel has: rolling compaction)
   e->d.lay = (e->d.CHT > TWX_SMALL_CHT && env_int("TWX_WINDOW", 1, 0, 1) != 0 && env_int("TWX_PAIR", 1, 0, 1) != 0 &&
-              env_int("TWX_ROLLING", 0, 0, 1) == 0 && step_tables().wocc_j[n]() > 0 && step_tables().wocc_f[n]() > 0)
+              env_int("TWX_ROLLING", 0, 0, 1) == 0 && step_tables().wocc_1[n]() > 0 && step_tables().wocc_f[n]() > 0)
                  ? 1 : 0;
   e->jpos = 0;
   e->period = env_int("TWX_JOURNAL_PERIOD", default_period(n), 1, twx::kJournalSlots);
@@ -542,9 +515,8 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     e->waves_win = e->waves_win_full = 0;
     e->win_one_lane = false;
     if (e->d.lay) {
-      e->win_one_lane = env_int("TWX_WIN_LANES", 1, 1, 2) == 1 && step_tables().wocc_1[n]() > 0;
-      e->waves_win = (cus > 0 ? cus : 256) *
-                     env_int("TWX_WIN_WAVES_PER_CU", e->win_one_lane ? step_tables().wocc_1[n]() : step_tables().wocc_j[n](), 1, 32);
+      e->win_one_lane = true;
+      e->waves_win = (cus > 0 ? cus : 256) * env_int("TWX_WIN_WAVES_PER_CU", step_tables().wocc_1[n](), 1, 32);
       e->waves_win_full = (cus > 0 ? cus : 256) * env_int("TWX_WIN_FULL_WAVES_PER_CU", step_tables().wocc_f[n](), 1, 32);
     }
   }

@@ -67,10 +67,7 @@ struct WinGeo {
   static constexpr int L_WIN = 32 * WSTR * 16, L_ALL = 32 * LFB;
   static constexpr int L_SLACK = 32;               // (a column read may touch the word after the last one)
   static constexpr int L_FB = 2 * LFB + L_SLACK;
-  static constexpr int lds_bytes(bool full) {
-    return full ? L_ROWS + L_ALL + L_SLACK : L_ROWS + L_ALL + L_SLACK + 128;
-  }
-  static constexpr int lds_bytes3() { return L_ROWS + L_WIN + L_SLACK + L_FB + 128; }  // step_window_kernel3
+  static constexpr int lds_bytes_full = L_ROWS + L_ALL + L_SLACK;  // step_window_full_kernel: rows + whole regions
   static_assert(NPC * BPI <= 64 && NK * BPI >= 32 && LFB % 16 == 0 && NW >= 1, "window fetch shape");
 };
 
@@ -853,736 +850,6 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
   }  // batch loop
 }
 
-// ---------------------------------------------------------------------------
-// The journal launches, software-pipelined.  The window fetch depends on the move, so a wave that
-// chooses, fetches and then applies sits through a whole memory latency per batch with nothing to do
-// (first version of this kernel: 128-150 us per launch at N=24 where step_pair_kernel takes 118-128).
-// Here a wave works on TWO batches: per iteration it
-//   1. moves what arrived during the last iteration into LDS: the rows of batch k+1 and the windows of batch k;
-//   2. requests the rows of batch k+2, CHOOSES the moves of batch k+1 and requests their windows;
-//   3. APPLIES the moves of batch k (crossing test, result, record) on the windows that are now there;
-// so every load has a whole phase of work between its issue and its use.  What batch k needs after its
-// move is chosen travels in registers (scalars, records, the knight neighbours of the mover's colour):
-// the apply phase never looks at the rows, which belong to batch k+1 by then.  The LDS image of the links +
-// flags regions is whole-board sized although only the windows are filled: records are replayed without
-// bounds tests (what falls outside a window lands in stale bytes nobody reads).
-// ---------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void step_window_pipe_body(char *__restrict__ state, long bpad, long batch,
-                                                      const int32_t *__restrict__ actions, int32_t *__restrict__ actions_out,
-                                                      uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-                                                      int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
-  using G = twx::Geo<N>;
-  using WG = WinGeo<N>;
-  constexpr int W = WG::W, RP = WG::RP, RSC = WG::RSC, RJ = WG::RJ, RA = WG::RA, LFB = WG::LFB, LFP = WG::LFP;
-  constexpr int NW = WG::NW, NPC = WG::NPC, BPI = WG::BPI, NK = WG::NK;
-  constexpr int BPW = 32;
-  constexpr int NJA = (RA + 1) / 2;  // row pairs: lane half h moves rows 2j + h
-  constexpr int RPH = (RP + 1) / 2;  // peg rows the lower lane scans (the upper one: the rest)
-  constexpr uint32_t kColMask = (1u << N) - 1u;
-  static_assert(NJA <= 8 && twx::kJournalChunks == 2 && W <= 32 && LFP <= 32, "layout");
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  typedef __attribute__((address_space(3))) uint32_t lds_u32;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)((lds_u32 *)lds);
-
-  const int lane = threadIdx.x;
-  const int h = lane >> 5, bl = lane & 31;
-  const bool up = h != 0;
-  const bool random = (flags & kFlagRandom) != 0;
-  const long nbatch = bpad / BPW;
-
-  const bool dyn = (flags & kFlagDynamic) != 0;
-  const int tgroup = blockIdx.x & (kTicketGroups - 1);
-  auto draw = [&]() -> uint32_t {
-    uint32_t t = 0u;
-    if (lane == 0)
-      t = __hip_atomic_fetch_add(ticket + tgroup * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-  };
-  auto ticket_batch = [&](uint32_t tv) -> long {
-    const uint32_t k = __builtin_amdgcn_readfirstlane(tv) - tbase.b[tgroup];
-    return uniform_long((long)nstatic * gridDim.x + (long)k * kTicketGroups + tgroup);
-  };
-  auto batch_of = [&](long i) -> long { return (flags & kFlagReverse) ? reversed_batch(i, nbatch) : i; };
-  auto tile_of = [&](long i) -> char * { return uniform_ptr(state + batch_of(i) * WG::TILE); };
-
-  // ---- LDS map (dwords): rows | 32 whole regions (only the windows are filled) | slack | 32 scratch words ----
-  constexpr int D_REG = WG::L_ROWS / 4;
-  constexpr int D_OFF = D_REG + (WG::L_ALL + WG::L_SLACK) / 4;  // window byte offsets of the 32 boards (inside tile and image alike)
-  constexpr int D_FBO = 0;  // the two whole regions of a flood pass: over the peg rows, which are dead by then
-  uint32_t *const rowme = lds + (bl << 2);
-  uint32_t *const sc = rowme + RSC * 128;
-  uint32_t *const jrow = lds + RJ * 128 + bl;
-  auto pegw = [&](int i) -> uint32_t * { return rowme + (i >> 1) * 128 + (i & 1) * 2; };
-  uint32_t *const wq = lds + D_REG + bl * (LFB / 4);  // word w of this board's links + flags: wq + 6 w
-
-  // ---- rows of a batch: lane half h moves rows 2j + h; journal rows only where a slot of the period lives ----
-  u32x4 rowv[NJA];  // (VGPRs, as everything here: with no AGPR operand in the kernel the whole budget of 256 is VGPRs)
-  uint32_t voff_rows = (uint32_t)bl * 16u + (uint32_t)h * 512u + 4096u;
-  asm volatile("" : "+v"(voff_rows));
-  auto row_wanted = [&](int r) -> bool {
-    if (r >= RA) return false;
-    if (r < RJ) return true;
-    return r == RJ ? (bl >> 3) < jpos : (bl >> 3) < jpos - 4;
-  };
-  auto load_rows = [&](const char *tile) {
-    static_for<0, NJA>([&](auto jt) {
-      constexpr int J = decltype(jt)::value;
-      if (2 * J + 1 < RJ || row_wanted(2 * J + h)) gload16iv<J * 1024 - 4096>(rowv[J], voff_rows, tile);
-    });
-  };
-  const uint32_t lds_rows = lds0 + (uint32_t)h * 512u + (uint32_t)bl * 16u;
-  auto fill_rows = [&]() {
-    static_for<0, NJA>([&](auto jt) {
-      constexpr int J = decltype(jt)::value;
-      const int r = 2 * J + h;
-      const bool want = r < RA && (r < RJ || (r == RJ ? jpos > 0 : jpos > 4));
-      if (want) lwrite16iv<J * 1024>(lds_rows, rowv[J]);
-    });
-  };
-
-  // loop-invariant per-lane constants of the split (step_pair_kernel)
-  const uint32_t hm = up ? 0xffffffffu : 0u;
-  const int link_lo = up ? 2 : 0;
-  const int wsh = up ? 16 : 0;
-  const int sgn = up ? 1 : -1;
-  const int dflip = up ? 0 : 7;
-  const int own_sh = 11 + 2 * h;
-  const int dlt0 = up ? twx::kDX[6] * N + twx::kDY[6] : twx::kDX[4] * N + twx::kDY[4];
-  const int dlt1 = up ? twx::kDX[7] * N + twx::kDY[7] : twx::kDX[5] * N + twx::kDY[5];
-  // window fetch: NPC consecutive lanes per board, BPI boards per instruction (every lane always loads)
-  const int fq0 = lane / NPC, fq = fq0 < BPI ? fq0 : BPI - 1;
-  const int fp = lane - fq0 * NPC;
-  const bool fon = fq0 < BPI;
-  u32x4 wv[NK];  // the windows under way (VGPRs)
-  // first piece of board column c's window (the window of a move at column x starts at column x - 3)
-  auto window_piece0 = [&](int x) -> int {
-    const int c_lo = x - 3 < 0 ? 0 : x - 3;
-    int w0 = (c_lo * N) >> 5;
-    w0 = w0 > W - NW ? W - NW : w0;
-    int piece0 = (24 * w0) >> 4;
-    return piece0 > LFP - NPC ? LFP - NPC : piece0;
-  };
-
-  STAMP_DECL;
-  long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
-  long round = 0;
-  uint32_t tv = (dyn && nstatic == 1) ? draw() : 0u;
-  load_rows(tile_of(idx));
-  vm_wait_all();
-  long idx_next = (dyn && nstatic == 1) ? ticket_batch(tv) : idx + gridDim.x;
-  bool drawn = dyn && round + 2 >= nstatic;
-  if (drawn) tv = draw();
-
-  // ---- what a batch carries from its select phase to its apply phase ----
-  bool c_valid = false;
-  long c_idx = 0;
-  int c_a = -1, c_pa = 0;
-  uint32_t c_counter = 0, c_move_one = 0, c_result = 0, c_swapped = 0, c_cand = 0;
-  uint32_t c_jr[twx::kJournalSlots - 1];
-#pragma unroll
-  for (int s = 0; s < twx::kJournalSlots - 1; s++) c_jr[s] = 0u;
-  uint32_t c_bits = 0;  // 1 act, 2 illegal, 4 was_reset, 8 swapnow, 16 inb, 32 the move fills the opponent's last cell
-  // ---- the deferred flood pass: boards (slots of the batch that was applied last), their tile, the region pieces under way ----
-  int d_fill = 0;  // boards waiting for their pass: 0, 1 (half-wave 0) or 2 (a pair: flooded after the next wait)
-  int d_s0 = 0, d_s1 = 0;
-  char *d_tile0 = state, *d_tile1 = state;
-  u32x4 d_pv;
-  uint32_t d_notes = 0;
-
-  while (idx < nbatch || c_valid || d_fill != 0) {
-    const bool have = idx < nbatch;  // (wave-uniform) is there a batch to choose moves for?
-    const long row = batch_of(have ? idx : 0) * BPW + bl;
-    const bool inb = have && row < batch;
-    int a_ext = -1;
-    if (!random && have) {  // external actions (twx_step): loaded, and waited for, before anything untracked is issued
-      if (inb) a_ext = actions[row];
-      asm volatile("" : "+v"(a_ext));
-    }
-#ifdef TWX_MARK
-    asm volatile("; MARK P1_fill");
-#endif
-    STAMP(0);  // loop end of the previous iteration
-    // ---- 1. what arrived: rows of the batch to choose for, windows of the batch to apply ----
-    if (have) fill_rows();
-    if (c_valid) {
-#pragma unroll
-      for (int k = 0; k < NK; k++) {  // (the image mirrors the tile: same byte offsets; D_OFF still holds this batch's)
-        const int b = k * BPI + fq;
-        if (fon && b < 32) lwrite16v(lds0 + lds[D_OFF + b] + (uint32_t)fp * 16u, wv[k]);
-      }
-    }
-    wave_sync();
-
-#ifdef TWX_MARK
-    asm volatile("; MARK P2_select_begin");
-#endif
-    STAMP(1);  // rows and windows -> LDS
-    // ---- 2. choose the moves of batch idx ----
-    int n_a = -1, n_pa = 0;
-    uint32_t n_counter = 0, n_move_one = 0, n_result = 0, n_swapped = 0, n_cand = 0, n_bits = 0;
-    uint32_t n_jr[twx::kJournalSlots - 1];
-#pragma unroll
-    for (int s = 0; s < twx::kJournalSlots - 1; s++) n_jr[s] = 0u;
-    if (have) {
-      const char *const tile_cur = tile_of(idx);
-      __builtin_amdgcn_sched_barrier(0);
-      load_rows(tile_of((idx_next < nbatch) ? idx_next : idx));  // (they have two phases to arrive)
-      __builtin_amdgcn_sched_barrier(0);
-      const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
-      uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
-      uint32_t result = sv.y & 0xffu, swapped = (sv.y >> 8) & 1u;
-      uint32_t episode = sv.z;
-      uint32_t jbase = (sv.y >> twx::kJBaseShift) & 15u;
-      uint32_t jr[twx::kJournalSlots - 1];
-#pragma unroll
-      for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-        const uint32_t e = (s < jpos) ? jrow[s * BPW] : 0u;  // (wave-uniform; slots from jpos on are stale or not loaded)
-        jr[s] = ((uint32_t)s >= jbase) ? e : 0u;
-      }
-#pragma unroll
-      for (int s = 0; s < twx::kJournalSlots - 1; s++)
-        if (s < jpos) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
-      const bool was_reset = random && (flags & kFlagAutoReset) && result != 0u && inb;
-      if (__ballot(was_reset)) {  // rare: one board in ~520 per step
-        if (was_reset) {
-          // ---- auto-reset (tb.cc:168-174, 209-276): empty pegs here, and the whole empty board to HBM -- rows
-          //      and scalars (with the journal base: the records before this launch's slot belong to the
-          //      finished game, the first move of the new one is in this launch's record) and the region of
-          //      the empty board.  Its window will still show the finished game: see `fresh` below ----
-#pragma unroll
-          for (int s = 0; s < twx::kJournalSlots - 1; s++) jr[s] = 0u;
-          jbase = (uint32_t)jpos;
-          counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
-          char *const tw = const_cast<char *>(tile_cur);
-#pragma unroll
-          for (int r = 0; r <= RSC; r++)
-            if ((r & 1) == h) {
-              const uint4 v = r < RP ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0u, jbase << twx::kJBaseShift, episode, 0u);
-              if (r < RP) *reinterpret_cast<uint4 *>(rowme + r * 128) = v;
-              tile_store<true>(reinterpret_cast<uint4 *>(tw + r * 512 + bl * 16), v);
-            }
-          uint32_t *const dst = reinterpret_cast<uint32_t *>(tw + WG::L_ROWS + bl * LFB);
-#pragma unroll
-          for (int i = 0; i < W; i++)
-            if ((i & 1) == h) {
-              __builtin_nontemporal_store(0u, dst + 6 * i + 0); __builtin_nontemporal_store(0u, dst + 6 * i + 1);
-              __builtin_nontemporal_store(0u, dst + 6 * i + 2); __builtin_nontemporal_store(0u, dst + 6 * i + 3);
-              __builtin_nontemporal_store(G::tab.init[twx::kPlaneStart * W + i], dst + 6 * i + 4);
-              __builtin_nontemporal_store(G::tab.init[twx::kPlaneEnd * W + i], dst + 6 * i + 5);
-            }
-        }
-        wave_sync();
-      }
-#ifdef TWX_MARK
-    asm volatile("; MARK P2b_pegreplay");
-#endif
-      // the records' peg bits (lower lane); move_one is final already (move 0 sets it, a swap is move 1)
-#pragma unroll
-      for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-        if (s < jpos) {  // wave-uniform
-          const uint32_t e = jr[s];
-          const int cell = (int)(e & 1023u);
-          const uint32_t bit = (1u << (cell & 31)) & (uint32_t)((int32_t)e >> 31);
-          if (__ballot((e & twx::kJSwap) != 0u))  // rare: undo red's first peg on a swap (tb.cc:450-455)
-            lds_and(pegw((int)(move_one >> 5)), (e & twx::kJSwap) ? ~(1u << (move_one & 31)) : 0xffffffffu);
-          if (!up) lds_or(pegw(cell >> 5) + ((e >> 10) & 1u), bit);
-        }
-      }
-      wave_sync();
-
-      const int player = (int)(counter & 1u);
-      const bool open = (result == 0u);
-#ifdef TWX_MARK
-    asm volatile("; MARK P2c_legal");
-#endif
-    STAMP(2);  // row prefetch issue, scalars, reset, peg replay
-      // ---- legal mask (tw.h:86-90): the lower lane scans peg rows 0..RPH-1, the upper one the rest ----
-      uint32_t m[2 * RPH];
-      const bool count_opp = __ballot(counter + 1u >= (uint32_t)(N * (N - 2))) != 0ull;
-      int n_opp = 0, n_mine = 0;
-#pragma unroll
-      for (int rr = 0; rr < RPH; rr++) {
-        const bool has_u = RPH + rr < RP;
-        const uint4 rb = *reinterpret_cast<const uint4 *>(rowme + ((up && has_u) ? RPH + rr : rr) * 128);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const int wl = 2 * rr + k, wu = 2 * (RPH + rr) + k;
-          const uint32_t r0l = wl < W ? G::tab.region[0][wl < W ? wl : 0] : 0u, r0u = (has_u && wu < W) ? G::tab.region[0][wu < W ? wu : 0] : 0u;
-          const uint32_t r1l = wl < W ? G::tab.region[1][wl < W ? wl : 0] : 0u, r1u = (has_u && wu < W) ? G::tab.region[1][wu < W ? wu : 0] : 0u;
-          const uint32_t reg_r = r0l ^ ((r0l ^ r0u) & hm), reg_b = r1l ^ ((r1l ^ r1u) & hm);
-          const uint32_t red = k ? rb.z : rb.x, blue = k ? rb.w : rb.y, occ = red | blue;
-          m[2 * rr + k] = (player ? reg_b : reg_r) & ~((counter == 1u) ? blue : occ);
-          n_mine += __popc(m[2 * rr + k]);
-          if (count_opp) n_opp += __popc((player ? reg_r : reg_b) & ~occ);
-        }
-      }
-      const PairVal pc = pair_swap((uint32_t)n_mine | ((uint32_t)n_opp << 10));
-      const int cnt_lo = (int)(pc.lo & 1023u), cnt = cnt_lo + (int)(pc.hi & 1023u);
-      const int cnt_opp = count_opp ? (int)((pc.lo >> 10) + (pc.hi >> 10)) : (1 << 20);
-
-#ifdef TWX_MARK
-    asm volatile("; MARK P2d_choose");
-#endif
-    STAMP(3);  // legal mask
-      int a = -1;
-      bool act = inb && open;
-      bool illegal = false;
-      if (random) {
-        act = act && cnt > 0;
-        const uint32_t hsh = twx::policy_hash(seed, first_id + (uint32_t)row, episode, counter);
-        const int k = (int)__umulhi(hsh, (uint32_t)cnt);
-        const bool lower_has_it = k < cnt_lo;
-        const int kk = up ? k - cnt_lo : k;
-        int cum = 0, wsel = 0, base = 0;
-        uint32_t msel = m[0];
-#pragma unroll
-        for (int ii = 0; ii < 2 * RPH; ii++) {
-          const bool ge = kk >= cum;
-          wsel = ge ? ii : wsel;
-          msel = ge ? m[ii] : msel;
-          base = ge ? cum : base;
-          cum += __popc(m[ii]);
-        }
-        const int a_half = ((up ? 2 * RPH : 0) + wsel) * 32 + select_bit(msel, kk - base);
-        const PairVal pa2 = pair_swap((uint32_t)a_half);
-        a = (int)(lower_has_it ? pa2.lo : pa2.hi);
-        if (!act) a = -1;
-      } else {
-        a = a_ext;
-        bool legal = false;
-        if (a >= 0 && a < N * N) {
-          const int ax = a / N, ay = a - ax * N;
-          const bool inreg = player ? (ay >= 1 && ay <= N - 2) : (ax >= 1 && ax <= N - 2);
-          const uint32_t bit = 1u << (a & 31);
-          const uint2 rb = *reinterpret_cast<const uint2 *>(pegw(a >> 5));
-          const bool occ = ((rb.y & bit) != 0u) || (counter != 1u && (rb.x & bit) != 0u);
-          legal = inreg && !occ;
-        }
-        illegal = inb && !(open && legal);
-        act = act && legal;
-      }
-      if (kAblate & 8) act = false;
-#ifdef TWX_MARK
-    asm volatile("; MARK P2e_window");
-#endif
-      // where the peg lands (tb.cc:462-473: a swap rotates it)
-      int pa = act ? a : 0;
-      const bool swapnow = act && (counter == 1u) && ((uint32_t)a == move_one);
-      if (swapnow) {
-        const int ax = a / N, ay = a - ax * N;
-        pa = ay * N + (N - 1 - ax);
-      }
-      const int x = pa / N, y = pa - x * N;
-      // ---- the window fetch: byte offsets of the 32 boards -> LDS, then NPC lanes per board ----
-      if (!up) lds[D_OFF + bl] = (uint32_t)(WG::L_ROWS + bl * LFB + 16 * window_piece0(x));
-      // knight neighbours of the mover's colour on this lane's side (tb.cc:517), from the pegs: the apply
-      // phase will not have these rows any more.  Bits in the UPPER lane's direction numbers, the lower
-      // lane's are the mirror images 7 - d
-      uint32_t cand = 0;
-#pragma unroll
-      for (int cj = 0; cj < 2; cj++) {
-        const int c = x + sgn * (cj + 1);
-        const bool ok = (unsigned)c < (unsigned)N;
-        const int o = (ok ? c : x) * N, sh = o & 31, wi = o >> 5;
-        const uint32_t own = ok ? (funnel(pegw(wi)[player], pegw(wi + 1 < W ? wi + 1 : wi)[player], sh) & kColMask) : 0u;
-        const int dy = 2 - cj;
-        const int dup = cj == 0 ? 0 : 1, ddn = cj == 0 ? 3 : 2;
-        const uint32_t wo = (own << 2) >> y;
-        cand |= (((wo >> (2 + dy)) & 1u) << (dup ^ dflip)) | (((wo >> (2 - dy)) & 1u) << (ddn ^ dflip));
-      }
-      // would this move take the opponent's last free cell (tb.cc:202-206)?
-      const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
-      const bool wdraw = counter + 1u > 2u && cnt_opp - (in_opp ? 1 : 0) == 0;
-      wave_sync();
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < NK; k++) {
-        const int b = k * BPI + fq < 32 ? k * BPI + fq : 31;
-        gload16v(wv[k], lds[D_OFF + b] + (uint32_t)fp * 16u, tile_cur);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      n_a = a; n_pa = pa;
-      n_counter = counter; n_move_one = move_one; n_result = result; n_swapped = swapped; n_cand = cand;
-#pragma unroll
-      for (int s = 0; s < twx::kJournalSlots - 1; s++) n_jr[s] = jr[s];
-      n_bits = (act ? 1u : 0u) | (illegal ? 2u : 0u) | (was_reset ? 4u : 0u) | (swapnow ? 8u : 0u) | (inb ? 16u : 0u) |
-               (wdraw ? 32u : 0u);
-    }
-
-#ifdef TWX_MARK
-    asm volatile("; MARK P3_apply_begin");
-#endif
-    STAMP(4);  // move, window offsets, neighbours, window fetch issue
-    // ---- 3. apply the moves of the carried batch on its windows ----
-    uint32_t entry = 0, c_pend = 0;  // this move's record; bit0 / bit1: flood START / END from the new peg
-    uint32_t o_result = c_result, o_swapped = c_swapped;
-    if (c_valid) {
-      const bool act = (c_bits & 1u) != 0u, fresh = (c_bits & 4u) != 0u, swapnow = (c_bits & 8u) != 0u;
-      const int pa = c_pa;
-      const int x = pa / N, y = pa - x * N;
-      const int player = (int)(c_counter & 1u);
-      char *const tile_c = tile_of(c_idx);
-      // the records' link / flag bits (split over the pair as in step_pair_kernel; no bounds: the image is whole)
-#pragma unroll
-      for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-        if (s < jpos) {  // wave-uniform
-          const uint32_t e = c_jr[s];
-          const int cell = (int)(e & 1023u);
-          const uint32_t valid = (uint32_t)((int32_t)e >> 31);
-          const uint32_t bit = (1u << (cell & 31)) & valid;
-          const uint32_t eo = e >> own_sh;
-          uint32_t *const g = wq + 6 * (cell >> 5);
-          lds_or2(g + link_lo, bit & (uint32_t)sbit(eo, 0), bit & (uint32_t)sbit(eo, 1));
-          lds_or2(g + 4, bit & hm & (uint32_t)sbit(e, 19), bit & hm & (uint32_t)sbit(e, 20));
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const uint32_t on = (uint32_t)sbit(eo, 4 + j) & valid;
-            const int tc = cell + (int)((uint32_t)(j ? dlt1 : dlt0) & on);
-            lds_or(wq + 6 * (tc >> 5) + link_lo + j, (1u << (tc & 31)) & on);
-          }
-          if (__ballot((e & (twx::kJFillStart | twx::kJFillEnd)) != 0u)) {
-            const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
-            const int t = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
-            const uint32_t on = (uint32_t)sbit(e >> 27, h) & valid;
-            const int tt = on ? t : cell;
-            lds_or(wq + 6 * (tt >> 5) + (up ? 5 : 4), (1u << (tt & 31)) & on);
-          }
-        }
-      }
-      wave_sync();
-#ifdef TWX_MARK
-    asm volatile("; MARK P3b_linkscan");
-#endif
-    STAMP(5);  // region replay
-      uint32_t pend = 0, fill1 = 0;
-      uint32_t counter = c_counter, move_one = c_move_one, result = c_result, swapped = c_swapped;
-      if (act) {
-        // ---- Board::ApplyAction (tb.cc:457-499), SetPegAndLinks (tb.cc:501-571) ----
-        const int piece0 = window_piece0(x);
-        auto win_has = [&](int w) -> bool { return (uint32_t)(24 * w - 16 * piece0) <= (uint32_t)(16 * NPC - 24); };
-        uint32_t *const gp = wq + 6 * (pa >> 5);
-        const uint32_t pbit = 1u << (pa & 31);
-        if (swapnow) swapped = 1u;
-        // border flags the empty cell already carries (tb.cc:223-231).  (The window of a board that was reset
-        // in its select phase still shows the finished game.  Its first peg has no neighbour of its colour, so
-        // nothing of the link scan counts; only these two flags would -- and no cell of the empty board
-        // carries both, so they cannot matter either)
-        const uint2 own_se = *reinterpret_cast<const uint2 *>(gp + 4);
-        const bool own_s = !fresh && (own_se.x & pbit) != 0u, own_e = !fresh && (own_se.y & pbit) != 0u;
-        // crossing window: board columns x-3..x+1, rows y-3..y+3 of this lane's two link planes
-        uint32_t win[twx::kWinCols];
-#pragma unroll
-        for (int cc = 0; cc < twx::kWinCols; cc++) {
-          const int c = x + cc - 3;
-          const bool ok = (unsigned)c < (unsigned)N;
-          const int o = (ok ? c : x) * N, sh = o & 31;
-          const uint32_t *const g = wq + 6 * (o >> 5) + link_lo;
-          const uint2 w0v = *reinterpret_cast<const uint2 *>(g), w1v = *reinterpret_cast<const uint2 *>(g + 6);
-          const uint32_t p0 = funnel(w0v.x, w1v.x, sh) & kColMask, p1 = funnel(w0v.y, w1v.y, sh) & kColMask;
-          const uint32_t v = (((p0 << 3) >> y) & 0x7fu) | ((((p1 << 3) >> y) & 0x7fu) << 8);
-          win[cc] = ok ? (v << wsh) : 0u;
-        }
-        // START / END flags of the knight neighbours on this lane's side
-        uint32_t ts = 0, te = 0;
-#pragma unroll
-        for (int cj = 0; cj < 2; cj++) {
-          const int c = x + sgn * (cj + 1);
-          const bool ok = (unsigned)c < (unsigned)N;
-          const int o = (ok ? c : x) * N, sh = o & 31, wi = o >> 5;
-          const uint32_t *const g = wq + 6 * wi + 4;
-          const uint2 f0 = *reinterpret_cast<const uint2 *>(g), f1 = *reinterpret_cast<const uint2 *>(g + 6);
-          const uint32_t fs = ok ? (funnel(f0.x, f1.x, sh) & kColMask) : 0u, fe = ok ? (funnel(f0.y, f1.y, sh) & kColMask) : 0u;
-          const int dy = 2 - cj;
-          const int dup = cj == 0 ? 0 : 1, ddn = cj == 0 ? 3 : 2;
-          const uint32_t wsf = (fs << 2) >> y, wef = (fe << 2) >> y;
-          ts |= (((wsf >> (2 + dy)) & 1u) << (dup ^ dflip)) | (((wsf >> (2 - dy)) & 1u) << (ddn ^ dflip));
-          te |= (((wef >> (2 + dy)) & 1u) << (dup ^ dflip)) | (((wef >> (2 - dy)) & 1u) << (ddn ^ dflip));
-        }
-        uint32_t blocked = 0;
-#pragma unroll
-        for (int d = 0; d < 8; d++) {  // crossing test (tb.cc:519-527): constant masks (twixt_geom.h)
-          uint32_t hit = 0;
-#pragma unroll
-          for (int i = 0; i < twx::kWinCols; i++) hit |= win[i] & twx::kCross.m[d][i];
-          blocked |= (hit != 0u ? 1u : 0u) << d;
-        }
-        const PairVal pq = pair_swap(c_cand | (ts << 8) | (te << 16) | (blocked << 24));
-        const uint32_t all = pq.lo | pq.hi;
-        const uint32_t cand = all & 0xffu;
-        ts = (all >> 8) & 0xffu; te = (all >> 16) & 0xffu; blocked = all >> 24;
-        const uint32_t linkm = cand & ~blocked;
-        // tb.cc:538-546: inherit START, else END, else remember a neutral neighbour
-        const uint32_t gain_s = linkm & ts, gain_e = linkm & ~ts & te, neutral = linkm & ~ts & ~te;
-        const bool p_s = own_s || gain_s;
-        const bool p_e = own_e || gain_e;
-        uint32_t want = (linkm && neutral) ? ((p_s ? 1u : 0u) | (p_e ? 2u : 0u)) : 0u;  // tb.cc:558-570
-        // the single-cell fill (half of all fills), settled on the pre-move planes when all of the neighbour's
-        // links lie inside the window; otherwise the long way
-        if (want && !(neutral & (neutral - 1u)) && (!(want & 1u) || (linkm & ~ts) == neutral) &&
-            (!(want & 2u) || (linkm & ~te) == neutral)) {
-          const int d = __ffs((int)neutral) - 1;
-          const int tx = x + (int)((twx::kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((twx::kDyPack >> (4 * d)) & 15u) - 2;
-          const int t = tx * N + ty;
-          bool seen = win_has(t >> 5);
-          const uint32_t *const gt = wq + 6 * ((seen ? t : pa) >> 5);
-          uint32_t other = (gt[0] | gt[1] | gt[2] | gt[3]) >> (t & 31);
-#pragma unroll
-          for (int e = 0; e < 4; e++) {  // links that END at t: stored at t - off[e]
-            const int sx = tx - twx::kDX[e], sy = ty - twx::kDY[e];
-            const bool valid = sx >= 0 && sy >= 0 && sy < N;
-            const int sc2 = valid ? sx * N + sy : pa;
-            const bool here = win_has(sc2 >> 5);
-            seen = seen && here;
-            const uint32_t w = wq[6 * ((here ? sc2 : pa) >> 5) + e];
-            other |= valid ? (w >> (sc2 & 31)) : 0u;
-          }
-          if (seen && !(other & 1u)) {
-            fill1 = ((uint32_t)d << twx::kJFillDirShift) | ((want & 1u) ? twx::kJFillStart : 0u) |
-                    ((want & 2u) ? twx::kJFillEnd : 0u);
-            want = 0u;
-          }
-        }
-        pend = want;
-        if (counter == 0u) move_one = (uint32_t)pa;  // tb.cc:485-488
-        counter += 1u;
-        // ---- UpdateResult (tb.cc:192-207) ----
-        if (p_s && p_e) result = player ? 2u : 1u;
-        else if (c_bits & 32u) result = 3u;
-        entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
-                (gain_s ? twx::kJGainStart : 0u) | (gain_e ? twx::kJGainEnd : 0u) | (swapnow ? twx::kJSwap : 0u) |
-                (result << twx::kJResultShift) | fill1;
-      }
-      o_result = result; o_swapped = swapped;
-      (void)move_one;
-
-#ifdef TWX_MARK
-    asm volatile("; MARK P4_flood");
-#endif
-      c_pend = pend;
-    }
-
-    STAMP(6);  // link scan, result, record
-    // What was requested in this iteration has had the apply phase to arrive: retire it here, before the
-    // stores are issued (loads and stores share one in-order counter).
-    vm_wait_all();
-    long idx_after = 0;
-    STAMP(7);  // wait for the rows and windows under way
-    if (have) {
-      idx_after = drawn ? ticket_batch(tv) : (long)blockIdx.x + (round + 2) * gridDim.x;
-      drawn = dyn && round + 3 >= nstatic && idx_next < nbatch;
-      if (drawn) tv = draw();
-    }
-    // ---- ExploreLocalGraph (tb.cc:573-588) for the fills that flag more than one cell (2.8 % of the moves, but
-    //      60 % of the batches have one).  Such a fill needs the board's WHOLE region.  Fetching it on the spot
-    //      made the wave sit through a memory latency in most batches (journal launches 125-142 us, 92-103 with
-    //      the fills left out), so the pass is DEFERRED by one iteration: the regions of the first two boards
-    //      are requested here and flooded after the next iteration's wait (the result of a move never
-    //      depends on its fill, and nobody reads these boards again in this launch).  Region pieces -> the
-    //      flood buffers (one piece per lane, LFP lanes per half-wave), the boards' records of this period and
-    //      the move itself replayed on them by eight lanes at once, flooded by the half-wave (lane = board
-    //      column), the flag words that changed stored as 8-byte pieces. ----
-    // notes of a pass, one register: lane j < 8 of half q holds record j of board s_q (slot jpos: the move
-    // itself), lane 8 its cell, lane 9 its pending flags -- read out of the boards' own lanes (no LDS round trip)
-    auto flood_notes = [&](uint32_t &notes, auto half, int sq) {  // the notes of board sq into half-wave `half`
-      constexpr int Q = decltype(half)::value;
-      static_for<0, 10>([&](auto it) {
-        constexpr int JJ = decltype(it)::value;
-        uint32_t mine;
-        if constexpr (JJ < twx::kJournalSlots) {
-          const uint32_t r = JJ < twx::kJournalSlots - 1 ? c_jr[JJ < twx::kJournalSlots - 1 ? JJ : 0] : 0u;
-          mine = JJ < jpos ? r : (JJ == jpos ? entry : 0u);
-        } else {
-          mine = JJ == 8 ? (uint32_t)c_pa : c_pend;
-        }
-        set_lane<32 * Q + JJ>(notes, __builtin_amdgcn_readlane((int)mine, sq));
-      });
-    };
-    using Half0 = std::integral_constant<int, 0>;
-    using Half1 = std::integral_constant<int, 1>;
-    auto flood_run = [&](uint32_t notes, int s0, int s1, bool two, char *tile0, char *tile1) {
-      const int c = bl;
-      const int src = up ? s1 : s0;
-      char *const tile = up ? tile1 : tile0;
-      const bool idle = up && !two;  // one board only: the upper half has nothing to do
-      const int spa = up ? __builtin_amdgcn_readlane((int)notes, 40) : __builtin_amdgcn_readlane((int)notes, 8);
-      const uint32_t spend = idle ? 0u : (uint32_t)(up ? __builtin_amdgcn_readlane((int)notes, 41) : __builtin_amdgcn_readlane((int)notes, 9));
-      uint32_t *const fb = lds + D_FBO + h * (LFB / 4);
-      if (bl < twx::kJournalSlots && !idle) record_on_region<N>(fb, notes);
-      wave_sync();
-      const int sx = spa / N, sy = spa - sx * N;
-      const bool ok = c < N;
-      const int o = (ok ? c : 0) * N, sh = o & 31, grp = o >> 5;
-      uint32_t *const g = fb + 6 * grp;
-      auto col = [&](int off) -> uint32_t {
-        const uint32_t v = funnel(g[off], g[off + 6], sh) & kColMask;
-        return ok ? v : 0u;
-      };
-      uint32_t lk[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) lk[e] = col(e);
-      bool changed = false;
-#pragma unroll
-      for (int f = 0; f < 2; f++) {
-        const bool en = (spend >> f) & 1u;  // uniform per half
-        if (!__ballot(en)) continue;
-        const int off = 4 + f;
-        const uint32_t flag0 = col(off);
-        uint32_t flag = flag0;
-        uint32_t front = (en && c == sx) ? (1u << sy) : 0u;
-        for (;;) {
-          uint32_t fresh_bits = 0u;
-#pragma unroll
-          for (int rep = 0; rep < 2; rep++) {  // two expansions per exit test
-            // forward: a frontier cell with link e reaches (c+dx, y+dy); backward: cell (c,y) whose link e ends
-            // in the frontier.  Columns move by DPP wave shifts, rows by bit shifts.  (Lanes 31 / 32 are
-            // neighbours for the shifts but column 31 does not exist: nothing crosses between the halves.)
-            const uint32_t a1 = ((front & lk[0]) << 2) | ((front & lk[3]) >> 2);
-            const uint32_t a2 = ((front & lk[1]) << 1) | ((front & lk[2]) >> 1);
-            uint32_t nb = wave_shr1(a1) | wave_shr1(wave_shr1(a2));
-            const uint32_t f1 = wave_shl1(front), f2 = wave_shl1(f1);
-            nb |= ((f1 >> 2) & lk[0]) | ((f2 >> 1) & lk[1]) | ((f2 << 1) & lk[2]) | ((f1 << 2) & lk[3]);
-            fresh_bits = ok ? (nb & ~flag & kColMask) : 0u;
-            flag |= fresh_bits;
-            front = fresh_bits;
-          }
-          if (__ballot(fresh_bits != 0u) == 0ull) break;
-        }
-        const uint32_t add = flag & ~flag0;
-        if (ok && add && en) {
-          changed = true;
-          lds_or(g + off, add << sh);
-          if (sh + N > 32) lds_or(g + off + 6, add >> (32 - sh));
-        }
-      }
-      wave_sync();
-      // the flag words this lane's column changed go back as 8-byte pieces { start_i, end_i } (two columns that
-      // share a word store the same bytes twice)
-      if (changed && !(kAblate & 2)) {
-        uint32_t *const dst = reinterpret_cast<uint32_t *>(tile + WG::L_ROWS + src * LFB + 24 * grp + 16);
-        const uint2 fv = *reinterpret_cast<const uint2 *>(g + 4);
-        __builtin_nontemporal_store(fv.x, dst);
-        __builtin_nontemporal_store(fv.y, dst + 1);
-        if (sh + N > 32) {
-          const uint2 fw = *reinterpret_cast<const uint2 *>(g + 10);
-          __builtin_nontemporal_store(fw.x, dst + 6);
-          __builtin_nontemporal_store(fw.y, dst + 7);
-        }
-      }
-      wave_sync();
-    };
-    // The pass waits until TWO boards have come together (one per half-wave) -- a batch has 0.9 such fills on
-    // average, and a pass with one idle half costs as much as a full one -- or until the batches run out.
-    auto region_loads = [&]() {  // (both halves: re-reading the waiting board's region keeps the two in one register)
-      const char *const a = (up ? d_tile1 : d_tile0) + (WG::L_ROWS + (up ? d_s1 : d_s0) * LFB + (bl < LFP ? bl : 0) * 16);
-      __builtin_amdgcn_sched_barrier(0);
-      gload16p(d_pv, a);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    if (d_fill == 2 || (d_fill == 1 && !have && !c_valid)) {  // requested an iteration ago or earlier: the pieces are here
-      const bool two = d_fill == 2;
-      if (bl < LFP && !(up && !two)) lwrite16v(lds0 + (uint32_t)(D_FBO * 4 + h * LFB + bl * 16), d_pv);
-      wave_sync();
-      flood_run(d_notes, d_s0, two ? d_s1 : d_s0, two, d_tile0, d_tile1);
-      d_fill = 0;
-    }
-    STAMP(8);  // ticket; the flood pass that was waiting
-    if (c_valid) {
-      uint64_t todo = __ballot(c_pend != 0u) & 0xffffffffull;  // (the upper lanes mirror the lower ones)
-      if (kAblate & 1) todo = 0ull;
-#ifdef TWX_DIAG_NOFLOOD
-      if (flags & (1 << 28)) todo = 0ull;  // diagnostic build: the code is there, the passes never run (results wrong)
-#endif
-      if (todo) {
-        char *const tile_c = tile_of(c_idx);
-        if (d_fill == 0) {
-          d_s0 = d_s1 = (int)__ffsll((unsigned long long)todo) - 1;
-          todo &= todo - 1;
-          d_tile0 = d_tile1 = tile_c;
-          flood_notes(d_notes, Half0{}, d_s0);
-          d_fill = 1;
-          if (!todo) region_loads();
-        }
-        if (todo && d_fill == 1) {
-          d_s1 = (int)__ffsll((unsigned long long)todo) - 1;
-          todo &= todo - 1;
-          d_tile1 = tile_c;
-          flood_notes(d_notes, Half1{}, d_s1);
-          d_fill = 2;
-          region_loads();
-        }
-        while (todo) {  // more fills in this batch than the waiting pass takes (rare): on the spot
-          const int s0 = (int)__ffsll((unsigned long long)todo) - 1;
-          todo &= todo - 1;
-          const bool two = todo != 0ull;
-          const int s1 = two ? (int)__ffsll((unsigned long long)todo) - 1 : s0;
-          if (two) todo &= todo - 1;
-          uint32_t notes2 = 0u;
-          flood_notes(notes2, Half0{}, s0);
-          flood_notes(notes2, Half1{}, s1);
-          u32x4 pv2;
-          __builtin_amdgcn_sched_barrier(0);
-          gload16v(pv2, (uint32_t)(WG::L_ROWS + (up ? s1 : s0) * LFB + (bl < LFP ? bl : 0) * 16), tile_c);
-          vm_wait_all();
-          if (bl < LFP && !(up && !two)) lwrite16v(lds0 + (uint32_t)(D_FBO * 4 + h * LFB + bl * 16), pv2);
-          __builtin_amdgcn_sched_barrier(0);
-          wave_sync();
-          flood_run(notes2, s0, s1, two, tile_c, tile_c);
-        }
-      }
-    }
-    STAMP(9);  // new fills: notes, region requests, passes on the spot
-    if (c_valid) {
-      // this move's record: all a step normally writes -- one dword per board, one 128-byte line per tile
-      char *const tile_c = tile_of(c_idx);
-      const long crow = batch_of(c_idx) * BPW + bl;
-      if (!(kAblate & 16) && !up)
-        tile_store_word<true>(reinterpret_cast<uint32_t *>(tile_c + RJ * 512 + jpos * (BPW * 4)) + bl, entry);
-      if ((c_bits & 16u) && !up) {
-        if (status) {
-          uint8_t st = (uint8_t)(o_result | (o_swapped << 5));
-          if (c_bits & 2u) st |= TWX_ST_ILLEGAL;
-          if (c_bits & 4u) st |= TWX_ST_RESET;
-          if (random && !(c_bits & 1u)) st |= TWX_ST_NOOP;
-          status[crow] = st;
-        }
-        if (actions_out) actions_out[crow] = c_a;
-      }
-    }
-    wave_sync();
-    STAMP(10);  // record and status stores
-    // the batch just chosen for becomes the carried one
-    c_valid = have;
-    c_idx = uniform_long(idx);
-    c_a = n_a; c_pa = n_pa; c_counter = n_counter; c_move_one = n_move_one; c_result = n_result; c_swapped = n_swapped;
-    c_cand = n_cand; c_bits = n_bits;
-#pragma unroll
-    for (int s = 0; s < twx::kJournalSlots - 1; s++) c_jr[s] = n_jr[s];
-    if (have) {  // (kept in scalar registers: the loop and its phases branch on them)
-      idx = uniform_long(idx_next);
-      idx_next = uniform_long(idx_after);
-      round++;
-    }
-  }  // batch loop
-  STAMP_FLUSH;
-}
-
-// journal launches: rows + a whole-board sized region image (19.7 KiB at N=24), eight waves per CU
-template <int N>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_window_kernel(
-    char *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
-    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
-  step_window_pipe_body<N>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, tbase, nstatic);
-}
-// journal launches without the pipeline, window-sized LDS image (12.6 KiB at N=24): twelve waves per CU (A/B: TWX_WIN_PIPE=0)
-template <int N>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(3, 3))) void step_window_kernel3(
-    char *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
-    int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-    int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
-  step_window_body<N, false>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, tbase, nstatic);
-}
 // compactions and flushes: the whole tile in LDS (19.5 KiB at N=24), eight waves per CU
 template <int N>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_window_full_kernel(
