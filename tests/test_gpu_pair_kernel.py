@@ -1,6 +1,8 @@
-"""GPU parity of the two step kernels of the big boards (N >= 19): step_pair_kernel (two lanes
-per board, the default for whole-batch launches) and step_kernel64 (one lane per board,
-TWX_PAIR=0), both against the CPU oracle -- every board, every step: actions, status bytes,
+"""GPU parity of the step kernels of the big boards (N >= 19) against the CPU oracle: the default path --
+split layout, step_window1_kernel (windowed journal launches, one lane per board) + step_window_full_kernel
+(compactions, flushes) -- and the two older ones on the chunk layout, step_pair_kernel (TWX_WINDOW=0: two lanes
+per board, whole boards streamed) and step_kernel64 (TWX_PAIR=0: one lane per board) -- every board, every
+step: actions, status bytes,
 twx_status in the middle of a journal period (the scalars chunk is then stale and the journal
 records carry counter / result / swapped), the full state at the end.  Also every journal
 period and batch order on the pair kernel, external actions with swaps and illegal moves, and
@@ -21,12 +23,16 @@ def torch_mod():
     return torch
 
 
-@pytest.mark.parametrize("n,batch,steps", [(19, 1000, 420), (21, 700, 150), (24, 1500, 640)])
-@pytest.mark.parametrize("pair", [1, 0])
-def test_every_step_against_the_oracle(torch_mod, n, batch, steps, pair, monkeypatch):
+KERNEL_PATHS = {"window": {}, "pair": {"TWX_WINDOW": "0"}, "lane": {"TWX_PAIR": "0"}}
+
+
+@pytest.mark.parametrize("n,batch,steps", [(19, 1000, 420), (21, 700, 150), (22, 330, 200), (24, 1500, 640)])
+@pytest.mark.parametrize("path", ["window", "pair", "lane"])
+def test_every_step_against_the_oracle(torch_mod, n, batch, steps, path, monkeypatch):
     import oracle_binding as ob
     torch = torch_mod
-    monkeypatch.setenv("TWX_PAIR", str(pair))
+    for k, v in KERNEL_PATHS[path].items():
+        monkeypatch.setenv(k, v)
     seed, first = 77, 4000
     env = make_env(n, batch, first=first)
     acts = np.zeros((batch, steps), dtype=np.int32)
@@ -108,11 +114,17 @@ def test_rolling_compaction_on_a_big_board(torch_mod, period, monkeypatch):
 
 
 @pytest.mark.parametrize("dynamic,nstatic", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 1000)])
-def test_pair_kernel_batch_order(torch_mod, dynamic, nstatic, monkeypatch):
-    """Ticket-drawn rounds on the pair kernel: one wave per CU over ~50k boards gives static
-    rounds, drawn rounds and a ragged last round; every board is stepped exactly once."""
+@pytest.mark.parametrize("path", ["window", "pair"])
+def test_pair_kernel_batch_order(torch_mod, dynamic, nstatic, path, monkeypatch):
+    """Ticket-drawn rounds on the window kernels (64- and 32-board batches) and on the pair kernel: one wave
+    per CU over ~50k boards gives static rounds, drawn rounds and a ragged last round; every board is stepped
+    exactly once."""
     import oracle_binding as ob
+    for k, v in KERNEL_PATHS[path].items():
+        monkeypatch.setenv(k, v)
     monkeypatch.setenv("TWX_PAIR_WAVES_PER_CU", "1")
+    monkeypatch.setenv("TWX_WIN_WAVES_PER_CU", "1")
+    monkeypatch.setenv("TWX_WIN_FULL_WAVES_PER_CU", "1")
     monkeypatch.setenv("TWX_DYNAMIC", str(dynamic))
     monkeypatch.setenv("TWX_DYNAMIC_STATIC", str(nstatic))
     n, batch, seed, first, steps = 19, 50021, 31, 12345, 40

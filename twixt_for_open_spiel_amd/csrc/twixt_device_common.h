@@ -88,6 +88,10 @@ __device__ unsigned long long g_stamps[16];
     if (threadIdx.x == 0)                                                                \
       for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_stamps[i_], st_acc[i_]);              \
   } while (0)
+#elif defined(TWX_MARK)  // phase boundaries as comments in the ISA (static instruction counts per phase)
+#define STAMP_DECL
+#define STAMP(i) asm volatile("; MARK P" #i)
+#define STAMP_FLUSH
 #else
 #define STAMP_DECL
 #define STAMP(i)

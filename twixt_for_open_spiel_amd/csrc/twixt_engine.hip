@@ -320,8 +320,12 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   int jarg = e->jpos;
   if (flush) {
     flags |= kFlagCompact;  // replay what is there, write everything, clear the journals
-  } else if (!whole_step || e->period == 1) {
-    flags |= kFlagCompact;  // no journaling: planes rewritten in place
+  } else if (!whole_step || e->period == 1 || (e->d.lay != 0 && (e->d.bpad / 64) * 4 <= (long)e->waves_win)) {
+    // no journaling: planes rewritten in place.  (Split layout, small batches -- a search's leaves: with fewer
+    // 64-board batches than a quarter of the resident waves a launch is one wave's latency, not bandwidth, and
+    // the pipelined journal kernel's extra iterations cost more than the bytes it saves: 15.3 against 10.5 us
+    // per step at N=24, B=16,384.)
+    flags |= kFlagCompact;
     jarg = 0;
   } else if (!e->rolling && e->jpos == e->period - 1) {
     flags |= kFlagCompact;
