@@ -69,6 +69,25 @@ def test_every_step_against_the_oracle(torch_mod, n, batch, steps, path, monkeyp
     env.close()
 
 
+def test_small_batches_rewrite_in_place(torch_mod, monkeypatch):
+    """The default routing of a small batch of a big board (a search's leaves): every step rewrites its boards
+    through step_window_full_kernel, the journal stays empty; same results, status queries in between."""
+    import oracle_binding as ob
+    monkeypatch.setenv("TWX_SMALL_BATCH_REWRITE", "1")
+    n, batch, seed, first, steps = 24, 3000, 5, 99, 130
+    env = make_env(n, batch, first=first)
+    stat = None
+    for t in range(steps):
+        _, stat = env.step_random(seed, True, want_actions=False)
+        if t % 17 == 3:
+            res, mc, _ = env.status()
+            assert np.array_equal(res.cpu().numpy(), stat.cpu().numpy() & 3)
+    ref = ob.rollout_batch(n, seed, first, batch, steps, True, want_trace=True)
+    assert np.array_equal(stat.cpu().numpy(), ref["status"][:, -1])
+    compare_planes(env, ref["planes"], what="small batch, rewritten in place")
+    env.close()
+
+
 @pytest.mark.parametrize("period,pingpong", [(1, 0), (2, 1), (3, 0), (4, 1), (5, 1), (6, 0), (7, 1), (8, 0), (8, 1)])
 def test_pair_kernel_journal_periods(torch_mod, period, pingpong, monkeypatch):
     """The log-structured state must be invisible on the pair kernel too: any compaction period

@@ -239,6 +239,7 @@ struct twx_env {
   // and of its rewriting instantiation
   int waves_win, waves_win_full;
   bool win_one_lane;  // journal launches: step_window1_kernel (one lane per board, 64 boards per wave)
+  bool small_rewrite;  // small batches skip the journal (TWX_SMALL_BATCH_REWRITE, default 1; 0: tests of the journal path)
   int cus;         // compute units of the device
   // dynamic batch order (TWX_DYNAMIC): device ticket counters (never reset) and the values
   // they will have when the next launch starts
@@ -320,7 +321,8 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   int jarg = e->jpos;
   if (flush) {
     flags |= kFlagCompact;  // replay what is there, write everything, clear the journals
-  } else if (!whole_step || e->period == 1 || (e->d.lay != 0 && (e->d.bpad / 64) * 4 <= (long)e->waves_win)) {
+  } else if (!whole_step || e->period == 1 ||
+             (e->d.lay != 0 && e->small_rewrite && (e->d.bpad / 64) * 4 <= (long)e->waves_win)) {
     // no journaling: planes rewritten in place.  (Split layout, small batches -- a search's leaves: with fewer
     // 64-board batches than a quarter of the resident waves a launch is one wave's latency, not bandwidth, and
     // the pipelined journal kernel's extra iterations cost more than the bytes it saves: 15.3 against 10.5 us
@@ -518,6 +520,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
     e->waves_pair = (cus > 0 ? cus : 256) * env_int("TWX_PAIR_WAVES_PER_CU", pocc > 0 ? pocc : 1, 1, 32);
     e->waves_win = e->waves_win_full = 0;
     e->win_one_lane = false;
+    e->small_rewrite = env_int("TWX_SMALL_BATCH_REWRITE", 1, 0, 1) != 0;
     if (e->d.lay) {
       e->win_one_lane = true;
       e->waves_win = (cus > 0 ? cus : 256) * env_int("TWX_WIN_WAVES_PER_CU", step_tables().wocc_1[n](), 1, 32);
