@@ -612,13 +612,13 @@ __device__ __forceinline__ void step_body(uint4 *__restrict__ state, long bpad, 
       STAMP(13);  // flood: iterations
       const uint32_t add = flag & ~flag0;
       if (ok && add) {
-        uint32_t dirty = 1u << grp;
+        uint32_t touched = 1u << grp;  // flag words this column changed
         lds_or(g + off, add << sh);
         if (sh + N > 32) {
           lds_or(g + off + GS, add >> (32 - sh));
-          dirty |= 2u << grp;
+          touched |= 2u << grp;
         }
-        lds_or(lds + (src << 2) + CS * RS + 3, dirty);
+        lds_or(lds + (src << 2) + CS * RS + 3, touched);
       }
       wave_sync();
       STAMP(14);  // flood: write-back

@@ -263,20 +263,20 @@ __global__ __launch_bounds__(kWave) void observation_kernel(const uint4 *__restr
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   f32x4 *o = reinterpret_cast<f32x4 *>(out + j * (long)(12 * npos));
   const uint32_t magic = (1u << 24) / (uint32_t)npos + 1u;  // e / npos == (e * magic) >> 24 for e < 12*npos <= 6336
-  for (int j = lane; j < 3 * npos; j += kWave) {  // 12*npos floats = 3*npos float4
+  for (int q = lane; q < 3 * npos; q += kWave) {  // 12*npos floats = 3*npos float4
     float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int e = 4 * j + q;
+    for (int qq = 0; qq < 4; qq++) {
+      const int e = 4 * q + qq;
       const int k = (int)(((uint32_t)e * magic) >> 24), pos = e - k * npos;
       const int colour = k >= 6 ? 1 : 0;
-      v[q] = ((feat[colour][pos] >> (k - 6 * colour)) & 1u) ? 1.0f : 0.0f;
+      v[qq] = ((feat[colour][pos] >> (k - 6 * colour)) & 1u) ? 1.0f : 0.0f;
     }
     const f32x4 vv = {v[0], v[1], v[2], v[3]};
 #if TWX_OBS_NT
-    __builtin_nontemporal_store(vv, o + j);  // write-only output, 25 KB per board: keep it out of the caches
+    __builtin_nontemporal_store(vv, o + q);  // write-only output, 25 KB per board: keep it out of the caches
 #else
-    o[j] = vv;
+    o[q] = vv;
 #endif
   }
 }

@@ -1,43 +1,28 @@
-// twixt_window_kernel.h -- step_window_kernel<N, FULL>: the whole-batch env step of the big boards (N >= 19)
-// on the SPLIT layout (twixt_device_common.h): a step streams a board's pegs, scalars and journal, chooses
-// the move, and only then fetches the links and border flags of the six board columns around it.
+// twixt_window_kernel.h -- the big boards (N >= 19) on the SPLIT layout (twixt_device_common.h): geometry of the
+// window of a move (WinGeo), the inline-asm load / LDS-write helpers of the windowed kernels, and
+// step_window_full_kernel<N>: the launches that rewrite everything (compactions, flushes, small batches).
 // Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
 #ifndef TWIXT_WINDOW_KERNEL_H_
 #define TWIXT_WINDOW_KERNEL_H_
 
-// Why.  A step reads every peg of its board (legal mask and k-th legal action, tw.h:86-90) but of the
-// links and border flags -- six of the eight planes, 432 of 592 bytes at N=24 -- only the crossing window
-// (board columns x-3..x+1, tb.cc:519-527) and the knight neighbours' flags (columns x-2..x+2,
-// tb.cc:538-546).  The step is bound by the 128-byte lines a CU's memory pipe moves, not by what it
-// computes, so the lines that are not needed are not fetched: per board and step 1.5 lines
-// of pegs / scalars / journal (coalesced rows of the tile) + about 2.1 lines of window (one contiguous run
-// of the board's board-major links+flags region, at a data-dependent offset) instead of 4.9
-// (tools/window_probe3.hip: the bare memory skeleton of this scheme runs in 0.086 ms per 2^20 boards
-// against 0.113 ms for whole tiles).  Rounds 1 and 2 had measured windowed steps as no faster; their
-// windows were gathers of 16-byte pieces out of [chunk][board] rows (a line per piece) and the probe
-// that was to settle it read half a tile by accident (profiles/r03_window_probe3.txt).
-//
-// One 64-thread workgroup = one wavefront = 32 boards, two lanes per board (lanes l and l+32 share board l),
-// as step_pair_kernel: the pair splits the legal-mask scan, the link planes (lower lane NNE / ENE and the
-// neighbours to the west, upper lane ESE / SSE and the neighbours to the east) and the journal replay.
-//
-//   FULL = false (journal launches, 7 of 8 at the default period): per batch
-//     1. rows (pegs, scalars, live journal slots) of the batch, prefetched into registers -> LDS;
-//     2. scalars advanced by the records, auto-reset, the records' PEG bits replayed; legal mask, move;
-//     3. the window: byte offsets of the 32 boards -> LDS, then NPC consecutive lanes per board fetch
-//        NPC x 16 B (six boards per instruction) -> LDS; the next batch's rows are requested behind it;
-//     4. the records' link / flag bits replayed inside the window (the rest of the board is not here);
-//        link scan + crossing test (tb.cc:501-555), result (tb.cc:192-207), the move's record;
-//     5. a multi-cell flood fill (tb.cc:573-588; 2.8 % of the moves) needs the whole board: fetched by
-//        the wave (27 lanes per board, two boards per pass), all records of the board and this move
-//        replayed on it by eight lanes at once, flooded by the wave (lane = board column), the flag
-//        words it changed stored as 8-byte pieces;
-//     6. write-back: the record -- 4 B per board, one 128-byte line per tile.  Nothing else: the
-//        move is not even applied to the LDS copy (nobody reads it again).
-//   FULL = true (compactions, flushes): the whole tile is streamed, records replayed everywhere, the
-//     move applied, floods run in place, everything written back.
-// Same journal, records, batch order (static rounds + tickets, XCD-preserving ping-pong) and results
-// as step_pair_kernel on the chunk layout.
+// The windowed step.  A step reads every peg of its board (legal mask and k-th legal action, tw.h:86-90) but of
+// the links and border flags -- six of the eight planes, 432 of 592 bytes at N=24 -- only the crossing window
+// (board columns x-3..x+1, tb.cc:519-527) and the knight neighbours' flags (columns x-2..x+2, tb.cc:538-546).
+// On the split layout a launch streams the rows of a tile (pegs, scalars, journal), chooses the move and only
+// then fetches the links + flags of the six board columns around it: one contiguous run of the board's
+// board-major region, about 2.1 lines of 128 B, instead of the region's 3.4 (tools/window_probe3.hip: the bare
+// memory skeleton runs in 0.086 ms per 2^20 boards against 0.113 ms for whole tiles; rounds 1 and 2 had measured
+// windowed steps as no faster -- their windows were gathers of 16-byte pieces out of [chunk][board] rows, a
+// line per piece, and the probe that was to settle it read half a tile by accident:
+// profiles/r03_window_probe3.txt).
+//   * journal launches (7 of 8 at the default period): step_window1_kernel, twixt_window1_kernel.h;
+//   * launches that rewrite the boards: step_window_full_kernel below -- the whole tile in LDS (rows and the 32
+//     regions: 19.5 KiB at N=24, eight waves per CU), two lanes per board as step_pair_kernel (the pair splits
+//     the legal-mask scan, the link planes -- lower lane NNE / ENE and the neighbours to the west, upper lane
+//     ESE / SSE and the neighbours to the east -- and the journal replay), records replayed everywhere, the move
+//     applied in LDS, flood fills run in place, pegs, scalars and regions written back.
+// Same journal, records, batch order (static rounds + tickets, XCD-preserving ping-pong) and results as
+// step_pair_kernel on the chunk layout.
 //
 // Reference lines: Board::ApplyAction tb.cc:457-499, SetPegAndLinks tb.cc:501-571, ExploreLocalGraph
 // tb.cc:573-588, UpdateResult tb.cc:192-207, LegalActions / DoApplyAction tw.h:86-104, Board::Board tb.cc:168-276.
@@ -59,20 +44,19 @@ struct WinGeo {
   // ... fetched as NPC 16-byte pieces from piece (24 w0) >> 4 on (24 w0 is 8 bytes off a piece for odd w0)
   static constexpr int NPC0 = (24 * NW + 8 + 15) / 16;
   static constexpr int NPC = NPC0 < LFP ? NPC0 : LFP;
-  static constexpr int BPI = 64 / NPC;             // boards one fetch instruction covers
-  static constexpr int NK = (32 + BPI - 1) / BPI;  // fetch instructions per batch
-  static constexpr int WSTR = NPC | 1;             // LDS stride of a board's window, pieces (odd: banks)
-  // LDS (bytes): rows | window or whole regions | two whole boards for the flood pass | window offsets
+  static constexpr int WSTR = NPC | 1;             // LDS stride of a board's window, pieces (odd: banks; the extra piece is padding)
+  // LDS of step_window_full_kernel (bytes): the rows, then the 32 whole regions as in the tile
   static constexpr int L_ROWS = RA * 512;
-  static constexpr int L_WIN = 32 * WSTR * 16, L_ALL = 32 * LFB;
+  static constexpr int L_ALL = 32 * LFB;
   static constexpr int L_SLACK = 32;               // (a column read may touch the word after the last one)
-  static constexpr int L_FB = 2 * LFB + L_SLACK;
-  static constexpr int lds_bytes_full = L_ROWS + L_ALL + L_SLACK;  // step_window_full_kernel: rows + whole regions
-  static_assert(NPC * BPI <= 64 && NK * BPI >= 32 && LFB % 16 == 0 && NW >= 1, "window fetch shape");
+  static constexpr int lds_bytes_full = L_ROWS + L_ALL + L_SLACK;
+  static_assert(LFB % 16 == 0 && NW >= 1 && NPC <= LFP, "window shape");
 };
 
-// 16 bytes: global -> AGPRs / AGPRs -> LDS (twixt_device_common.h "Tile I/O": the compiler does not see
-// these loads; the kernel waits for them explicitly)
+// ---- 16 bytes: global -> registers -> LDS, as inline asm (twixt_device_common.h "Tile I/O": the compiler does
+//      not see these loads; the kernels wait for them explicitly, and every load with a scalar base carries the
+//      wait states of the VALU-writes-SGPR hazard: TWX_SGPR_HAZARD_NOP) ----
+// step_window_full_kernel keeps its prefetched tile in AGPRs ("a") ...
 __device__ __forceinline__ void gload16(u32x4 &dst, uint32_t voff, const void *base) {
   asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2" : "=a"(dst) : "v"(voff), "s"(base) : "memory");
 }
@@ -83,49 +67,40 @@ __device__ __forceinline__ void gload16i(u32x4 &dst, uint32_t voff, const void *
 __device__ __forceinline__ void lwrite16(uint32_t lds_addr, const u32x4 &v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(v) : "memory");
 }
-// (the same through VGPRs: the short-lived window / flood pieces)
-__device__ __forceinline__ void gload16v(u32x4 &dst, uint32_t voff, const void *base) {
-  asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+template <int IMM>
+__device__ __forceinline__ void lwrite16i(uint32_t lds_addr, const u32x4 &v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), "a"(v), "n"(IMM) : "memory");
 }
-__device__ __forceinline__ void lwrite16v(uint32_t lds_addr, const u32x4 &v) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
-}
-// (per-lane 64-bit address)
-__device__ __forceinline__ void gload16p(u32x4 &dst, const void *addr) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
-}
+// ... step_window1_kernel has no AGPR operand at all, so that its whole budget of 256 registers is VGPRs ("v")
 template <int IMM>
 __device__ __forceinline__ void gload16iv(u32x4 &dst, uint32_t voff, const void *base) {
   asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void gload16p(u32x4 &dst, const void *addr) {  // (per-lane 64-bit address)
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lwrite16v(uint32_t lds_addr, const u32x4 &v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
 }
 template <int IMM>
 __device__ __forceinline__ void lwrite16iv(uint32_t lds_addr, const u32x4 &v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), "v"(v), "n"(IMM) : "memory");
 }
+// a wave-uniform value the compiler could not prove uniform (a batch index that went around the pipelined
+// loop): back into scalar registers, where the loop's branches and the loads' base want it
 __device__ __forceinline__ long uniform_long(long v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
   return (long)(((uint64_t)hi << 32) | lo);
 }
-template <int IMM>
-__device__ __forceinline__ void lwrite16i(uint32_t lds_addr, const u32x4 &v) {
-  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), "a"(v), "n"(IMM) : "memory");
-}
-// a wave-uniform pointer the compiler could not prove uniform (a batch index that went around the
-// pipelined loop): back into scalar registers, where the loads above want their base
 __device__ __forceinline__ char *uniform_ptr(const char *p) {
-  const uint64_t v = (uint64_t)(uintptr_t)p;
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-  return reinterpret_cast<char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+  return reinterpret_cast<char *>((uintptr_t)uniform_long((long)(uintptr_t)p));
 }
 // v[LANE] = a wave-uniform value (v_writelane_b32)
 template <int LANE>
 __device__ __forceinline__ void set_lane(uint32_t &v, int uniform_value) {
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(uniform_value), "n"(LANE));
 }
-template <int CNT>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); }
 
 // All link / flag updates of one journal record on a WHOLE board's links + flags region in LDS (fb: word i,
 // plane p at fb[6 i + p - 2]); one lane does the whole record (the flood pass: eight lanes, eight records).
@@ -155,19 +130,18 @@ __device__ __forceinline__ void record_on_region(uint32_t *fb, uint32_t e) {
   }
 }
 
-template <int N, bool FULL>
-__device__ __forceinline__ void step_window_body(char *__restrict__ state, long bpad, long batch,
+template <int N>
+__device__ __forceinline__ void step_window_full_body(char *__restrict__ state, long bpad, long batch,
                                                  const int32_t *__restrict__ actions, int32_t *__restrict__ actions_out,
                                                  uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
                                                  int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
   using G = twx::Geo<N>;
   using WG = WinGeo<N>;
   constexpr int W = WG::W, RP = WG::RP, RSC = WG::RSC, RJ = WG::RJ, RA = WG::RA, LFB = WG::LFB, LFP = WG::LFP;
-  constexpr int NW = WG::NW, NPC = WG::NPC, BPI = WG::BPI, NK = WG::NK, WSTR = WG::WSTR;
   constexpr int BPW = 32;               // boards per wave
   constexpr int NJA = (RA + 1) / 2;     // row pairs: lane half h moves rows 2j + h
   constexpr int RPH = (RP + 1) / 2;     // peg rows the lower lane scans (the upper one: the rest)
-  constexpr int NLF = (32 * LFP + 63) / 64;  // FULL: instructions that move the tile's links + flags regions
+  constexpr int NLF = (32 * LFP + 63) / 64;  // instructions that move the tile's links + flags regions
   constexpr uint32_t kColMask = (1u << N) - 1u;
   static_assert(NJA <= 8 && twx::kJournalChunks == 2 && W <= 32, "layout");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -200,68 +174,42 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
   auto tile_of = [&](long i) -> char * { return state + batch_of(i) * WG::TILE; };
 
   // ---- LDS map (dwords) ----
-  constexpr int D_REG = WG::L_ROWS / 4;                      // window area / whole regions
-  constexpr int D_FB = D_REG + (WG::L_WIN + WG::L_SLACK) / 4;  // (!FULL) two whole boards of the flood pass
-  constexpr int D_OFF = D_FB + WG::L_FB / 4;                 // (!FULL) window byte offsets of the 32 boards
+  constexpr int D_REG = WG::L_ROWS / 4;                      // the 32 whole regions, as in the tile
   uint32_t *const rowme = lds + (bl << 2);                   // this board's 16 bytes of row r: rowme + 128 r
   uint32_t *const sc = rowme + RSC * 128;                    // scalars
   uint32_t *const jrow = lds + RJ * 128 + bl;                // journal record s of this board: jrow[32 s]
   // peg word i of player p: rowme[(i >> 1) * 128 + (i & 1) * 2 + p]
   auto pegw = [&](int i) -> uint32_t * { return rowme + (i >> 1) * 128 + (i & 1) * 2; };
 
-  // ---- prefetch of a batch's rows: lane half h moves rows 2j + h; journal rows only where a slot of the
-  //      running period lives (a row is four 128-byte lines, one per slot: lanes 8s..8s+7 move slot s) ----
+  // ---- prefetch of a batch's rows: lane half h moves rows 2j + h (the journal rows whole: a flush reads
+  //      every slot up to jpos, and nobody minds the rest) ----
   u32x4 rowv[NJA];
   uint32_t voff_rows = (uint32_t)bl * 16u + (uint32_t)h * 512u + 4096u;
   asm volatile("" : "+v"(voff_rows));
-  auto row_wanted = [&](int r) -> bool {  // does this lane load its 16 bytes of row r?
-    if (r >= RA) return false;
-    if (FULL || r < RJ) return true;  // (FULL: the journal rows whole -- a flush reads every slot up to jpos)
-    return r == RJ ? (bl >> 3) < jpos : (bl >> 3) < jpos - 4;
-  };
-  // (journal launches: the row pairs that hold a journal row are conditional per lane and are issued
-  // FIRST, so that the number of unconditional ones behind the window fetch is known: kUncond)
-  constexpr int kFirstCond = FULL ? NJA : RJ / 2;  // first row pair with a journal row in it
-  constexpr int kUncond = kFirstCond;              // row pairs 0..kFirstCond-1: pegs (and scalars) only
   auto load_rows = [&](const char *tile) {
     static_for<0, NJA>([&](auto jt) {
-      constexpr int JJ = decltype(jt)::value;
-      constexpr int J = JJ < NJA - kFirstCond ? kFirstCond + JJ : JJ - (NJA - kFirstCond);  // conditional pairs first
-      if (J < kFirstCond || row_wanted(2 * J + h)) {
-        if constexpr (FULL) gload16i<J * 1024 - 4096>(rowv[J], voff_rows, tile);
-        else gload16iv<J * 1024 - 4096>(rowv[J], voff_rows, tile);  // (journal launches: no AGPR operand, all 168 registers are VGPRs)
-      }
+      constexpr int J = decltype(jt)::value;
+      if (2 * J + h < RA) gload16i<J * 1024 - 4096>(rowv[J], voff_rows, tile);
     });
   };
   const uint32_t lds_rows = lds0 + (uint32_t)h * 512u + (uint32_t)bl * 16u;
   auto fill_rows = [&]() {
     static_for<0, NJA>([&](auto jt) {
       constexpr int J = decltype(jt)::value;
-      const int r = 2 * J + h;
-      // (journal rows: only when a slot of the running period lives there; lanes that did not load their
-      // 16 bytes of such a row write a stale register: those slots are never read)
-      const bool want = r < RA && (FULL || r < RJ || (r == RJ ? jpos > 0 : jpos > 4));
-      if (want) {
-        if constexpr (FULL) lwrite16i<J * 1024>(lds_rows, rowv[J]);
-        else lwrite16iv<J * 1024>(lds_rows, rowv[J]);
-      }
+      if (2 * J + h < RA) lwrite16i<J * 1024>(lds_rows, rowv[J]);
     });
   };
-  // ---- FULL: the tile's 32 links + flags regions, contiguous in HBM and in LDS alike ----
-  u32x4 lfv[FULL ? NLF : 1];
+  // ---- the tile's 32 links + flags regions, contiguous in HBM and in LDS alike ----
+  u32x4 lfv[NLF];
   auto load_regions = [&](const char *tile) {
-    if constexpr (FULL) {
 #pragma unroll
-      for (int k = 0; k < NLF; k++)
-        if (k * 64 + lane < 32 * LFP) gload16(lfv[k], (uint32_t)(WG::L_ROWS + (k * 64 + lane) * 16), tile);
-    }
+    for (int k = 0; k < NLF; k++)
+      if (k * 64 + lane < 32 * LFP) gload16(lfv[k], (uint32_t)(WG::L_ROWS + (k * 64 + lane) * 16), tile);
   };
   auto fill_regions = [&]() {
-    if constexpr (FULL) {
 #pragma unroll
-      for (int k = 0; k < NLF; k++)
-        if (k * 64 + lane < 32 * LFP) lwrite16(lds0 + (uint32_t)(WG::L_ROWS + (k * 64 + lane) * 16), lfv[k]);
-    }
+    for (int k = 0; k < NLF; k++)
+      if (k * 64 + lane < 32 * LFP) lwrite16(lds0 + (uint32_t)(WG::L_ROWS + (k * 64 + lane) * 16), lfv[k]);
   };
 
   long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
@@ -285,11 +233,6 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
   const int own_sh = 11 + 2 * h;            // record bit of link 2h
   const int dlt0 = up ? twx::kDX[6] * N + twx::kDY[6] : twx::kDX[4] * N + twx::kDY[4];
   const int dlt1 = up ? twx::kDX[7] * N + twx::kDY[7] : twx::kDX[5] * N + twx::kDY[5];
-  // window fetch: NPC consecutive lanes per board, BPI boards per instruction (the last lanes of an
-  // instruction repeat a piece: every lane always loads, so every register is always written)
-  const int fq0 = lane / NPC, fq = fq0 < BPI ? fq0 : BPI - 1;
-  const int fp = lane - fq0 * NPC;          // piece of the window (< NPC also for the repeating lanes: 64 - NPC BPI < NPC)
-  const bool fon = fq0 < BPI;
 
   while (idx < nbatch) {
     const long row = batch_of(idx) * BPW + bl;  // = board: whole-batch launches only
@@ -304,12 +247,10 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
     fill_regions();
     wave_sync();
     const char *const tile_next = tile_of((idx_next < nbatch) ? idx_next : idx);
-    if constexpr (FULL) {  // the whole next tile behind the step, as step_pair_kernel
-      __builtin_amdgcn_sched_barrier(0);
-      load_rows(tile_next);
-      load_regions(tile_next);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    __builtin_amdgcn_sched_barrier(0);  // the whole next tile behind the step, as step_pair_kernel
+    load_rows(tile_next);
+    load_regions(tile_next);
+    __builtin_amdgcn_sched_barrier(0);
 
     const uint4 sv = *reinterpret_cast<const uint4 *>(sc);
     uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
@@ -329,22 +270,19 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
     const bool was_reset = random && (flags & kFlagAutoReset) && result != 0u && inb;
     if (__ballot(was_reset)) {  // rare: one board in ~520 per step
       if (was_reset) {
-        // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276): the pegs here; the links + flags region is
-        //      written to HBM from the constants below and, FULL, into the LDS copy ----
+        // ---- auto-reset: Board::Board (tb.cc:168-174, 209-276) in the LDS copy, each lane its half ----
 #pragma unroll
         for (int r = 0; r < RP; r++)
           if ((r & 1) == h) *reinterpret_cast<uint4 *>(rowme + r * 128) = make_uint4(0u, 0u, 0u, 0u);
-        if constexpr (FULL) {
-          uint32_t *const fbme = lds + D_REG + bl * (LFB / 4);
+        uint32_t *const fbme = lds + D_REG + bl * (LFB / 4);
 #pragma unroll
-          for (int i = 0; i < W; i++)
-            if ((i & 1) == h) {
-              *reinterpret_cast<uint2 *>(fbme + 6 * i) = make_uint2(0u, 0u);
-              *reinterpret_cast<uint2 *>(fbme + 6 * i + 2) = make_uint2(0u, 0u);
-              *reinterpret_cast<uint2 *>(fbme + 6 * i + 4) =
-                  make_uint2(G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
-            }
-        }
+        for (int i = 0; i < W; i++)
+          if ((i & 1) == h) {
+            *reinterpret_cast<uint2 *>(fbme + 6 * i) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(fbme + 6 * i + 2) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(fbme + 6 * i + 4) =
+                make_uint2(G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
+          }
 #pragma unroll
         for (int s = 0; s < twx::kJournalSlots; s++) jr[s] = 0u;  // nothing to replay on the empty board
         jbase = (uint32_t)jpos;  // the records before this launch's slot belong to the finished game
@@ -352,60 +290,39 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
       }
       wave_sync();
     }
-    // ---- replay, part 1: the records' peg bits (lower lane) and, FULL, everything else too ----
-    //      (move_one is final already: it is set by move 0 and a swap is move 1)
-    uint32_t *const fball = lds + D_REG + bl * (LFB / 4);  // FULL: this board's whole region
-    // journal launches: the window of this board, known once the move is
-    int win_w0 = 0;       // a word that is certainly inside
-    uint32_t win_lo = 0;  // first byte of the region that is in the window area
-    auto win_has = [&](int w) -> bool { return (uint32_t)(24 * w - (int)win_lo) <= (uint32_t)(16 * NPC - 24); };
-    auto replay_region = [&](uint32_t *wq, auto checked) {
-      // links / flags of the records into a region image: word w at wq + 6 w.  checked: only the words inside
-      // this board's window are there; what a record changes elsewhere is skipped (a no-op OR into win_w0).
-      // Work of one record, split over the pair as in step_pair_kernel: lower lane links 0, 1 (west end = the
-      // cell) and 4, 5 (west end = the target), the single-cell fill's START; upper lane START / END gained,
-      // links 2, 3 and 6, 7, the fill's END; conditions are sign-extended record bits ANDed into the values.
-      constexpr bool CHK = decltype(checked)::value;
-      auto word_at = [&](int w, uint32_t &keep) -> uint32_t * {
-        if constexpr (CHK) {
-          const bool ok = win_has(w);
-          keep = ok ? 0xffffffffu : 0u;
-          return wq + 6 * (ok ? w : win_w0);
-        } else {
-          keep = 0xffffffffu;
-          return wq + 6 * w;
+    // ---- replay the redo journal: slots 0..jpos-1 (move_one is final already: it is set by move 0 and a swap
+    //      is move 1).  Work of one record, split over the pair as in step_pair_kernel: lower lane the peg,
+    //      links 0, 1 (west end = the cell) and 4, 5 (west end = the target), the single-cell fill's START;
+    //      upper lane START / END gained, links 2, 3 and 6, 7, the fill's END; conditions are sign-extended
+    //      record bits ANDed into the values ----
+    uint32_t *const wq = lds + D_REG + bl * (LFB / 4);  // word w of this board's links + flags: wq + 6 w
+#pragma unroll
+    for (int s = 0; s < twx::kJournalSlots - 1; s++) {
+      if (s < jpos) {  // wave-uniform
+        const uint32_t e = jr[s];
+        const int cell = (int)(e & 1023u);
+        const uint32_t valid = (uint32_t)((int32_t)e >> 31);
+        const uint32_t bit = (1u << (cell & 31)) & valid;  // empty record: every OR is a no-op
+        const uint32_t eo = e >> own_sh;  // bits 0, 1: this lane's links at the cell; bits 4, 5: at the targets
+        uint32_t *const g = wq + 6 * (cell >> 5);
+        lds_or2(g + link_lo, bit & (uint32_t)sbit(eo, 0), bit & (uint32_t)sbit(eo, 1));
+        lds_or2(g + 4, bit & hm & (uint32_t)sbit(e, 19), bit & hm & (uint32_t)sbit(e, 20));
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const uint32_t on = (uint32_t)sbit(eo, 4 + j) & valid;
+          const int tc = cell + (int)((uint32_t)(j ? dlt1 : dlt0) & on);
+          lds_or(wq + 6 * (tc >> 5) + link_lo + j, (1u << (tc & 31)) & on);
         }
-      };
-#pragma unroll
-      for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-        if (s < jpos) {  // wave-uniform
-          const uint32_t e = jr[s];
-          const int cell = (int)(e & 1023u);
-          const uint32_t bit = (1u << (cell & 31)) & (uint32_t)((int32_t)e >> 31);  // empty record: every OR is a no-op
-          const uint32_t eo = e >> own_sh;  // bits 0, 1: this lane's links at the cell; bits 4, 5: at the targets
-          uint32_t keep;
-          uint32_t *const g = word_at(cell >> 5, keep);
-          lds_or2(g + link_lo, bit & keep & (uint32_t)sbit(eo, 0), bit & keep & (uint32_t)sbit(eo, 1));
-          lds_or2(g + 4, bit & keep & hm & (uint32_t)sbit(e, 19), bit & keep & hm & (uint32_t)sbit(e, 20));
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const uint32_t on = (uint32_t)sbit(eo, 4 + j) & (uint32_t)((int32_t)e >> 31);
-            const int tc = cell + (int)((uint32_t)(j ? dlt1 : dlt0) & on);
-            uint32_t *const gt = word_at(tc >> 5, keep);
-            lds_or(gt + link_lo + j, (1u << (tc & 31)) & on & keep);
-          }
-          if (__ballot((e & (twx::kJFillStart | twx::kJFillEnd)) != 0u)) {
-            // the single neighbour a fill flagged: lower lane START, upper lane END
-            const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
-            const int t = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
-            const uint32_t on = (uint32_t)sbit(e >> 27, h) & (uint32_t)((int32_t)e >> 31);
-            const int tt = on ? t : cell;  // (no fill: t is meaningless and may lie outside the board)
-            uint32_t *const gt = word_at(tt >> 5, keep);
-            lds_or(gt + (up ? 5 : 4), (1u << (tt & 31)) & on & keep);
-          }
+        if (__ballot((e & (twx::kJFillStart | twx::kJFillEnd)) != 0u)) {
+          // the single neighbour a fill flagged: lower lane START, upper lane END
+          const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
+          const int t = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
+          const uint32_t on = (uint32_t)sbit(e >> 27, h) & valid;
+          const int tt = on ? t : cell;  // (no fill: t is meaningless and may lie outside the board)
+          lds_or(wq + 6 * (tt >> 5) + (up ? 5 : 4), (1u << (tt & 31)) & on);
         }
       }
-    };
+    }
 #pragma unroll
     for (int s = 0; s < twx::kJournalSlots - 1; s++) {
       if (s < jpos) {  // wave-uniform
@@ -417,7 +334,6 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
         if (!up) lds_or(pegw(cell >> 5) + ((e >> 10) & 1u), bit);
       }
     }
-    if constexpr (FULL) replay_region(fball, std::false_type{});
     wave_sync();
 
     const int player = (int)(counter & 1u);
@@ -489,7 +405,7 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
       act = act && legal;
     }
 
-    // ---- where the peg lands (tb.cc:462-473: a swap rotates it), and with that the window ----
+    // ---- where the peg lands (tb.cc:462-473: a swap rotates it) ----
     int pa = act ? a : 0;
     const bool swapnow = act && (counter == 1u) && ((uint32_t)a == move_one);
     if (swapnow) {
@@ -497,62 +413,19 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
       pa = ay * N + (N - 1 - ax);
     }
     const int x = pa / N, y = pa - x * N;
-    uint32_t *wq;  // word w of this board's links + flags: wq + 6 w (journal launches: inside the window only)
-    if constexpr (FULL) {
-      wq = fball;
-    } else {
-      const int c_lo = x - 3 < 0 ? 0 : x - 3;
-      int w0 = (c_lo * N) >> 5;
-      w0 = w0 > W - NW ? W - NW : w0;
-      int piece0 = (24 * w0) >> 4;
-      piece0 = piece0 > LFP - NPC ? LFP - NPC : piece0;
-      win_w0 = w0;
-      win_lo = (uint32_t)(16 * piece0);
-      wq = lds + D_REG + bl * (WSTR * 4) - 4 * piece0;
-      // ---- the window fetch: byte offsets of the 32 boards -> LDS, then NPC lanes per board ----
-      if (!up) lds[D_OFF + bl] = (uint32_t)(WG::L_ROWS + bl * LFB) + win_lo;
-      wave_sync();
-      u32x4 wv[NK];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < NK; k++) {
-        const int b = k * BPI + fq < 32 ? k * BPI + fq : 31;
-        gload16v(wv[k], lds[D_OFF + b] + (uint32_t)fp * 16u, tile_cur_c);
-      }
-      // ... and behind it the rows of the next batch (they have the rest of the step to arrive)
-      load_rows(tile_next);
-      vm_wait<kUncond>();  // the window is here (loads return in order); the unconditional row pairs may still fly
-#pragma unroll
-      for (int k = 0; k < NK; k++) {
-        const int b = k * BPI + fq;
-        if (fon && b < 32) lwrite16v(lds0 + (uint32_t)(WG::L_ROWS + (b * WSTR + fp) * 16), wv[k]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      wave_sync();
-      replay_region(wq, std::true_type{});
-      wave_sync();
-    }
     if (kAblate & 8) act = false;
 
     uint32_t pend = 0;   // bit0: flood START from pa, bit1: flood END from pa
-    uint32_t entry = 0;  // journal record of this move
-    uint32_t fill1 = 0;  // single-cell fill of the shortcut below, as record bits
     if (act) {
       // ---- Board::ApplyAction (tb.cc:457-499) ----
       uint32_t *const gp = wq + 6 * (pa >> 5);
       const uint32_t pbit = 1u << (pa & 31);
       if (swapnow) swapped = 1u;
-      if constexpr (FULL) {
-        if (swapnow) lds_and(pegw(a >> 5), ~(1u << (a & 31)));  // tb.cc:450-455: undo red's first peg
-        if (!up) lds_or(pegw(pa >> 5) + player, pbit);          // tb.cc:507-508 set peg
-      }
+      if (swapnow) lds_and(pegw(a >> 5), ~(1u << (a & 31)));  // tb.cc:450-455: undo red's first peg
+      if (!up) lds_or(pegw(pa >> 5) + player, pbit);          // tb.cc:507-508 set peg
       // border flags the empty cell already carries (tb.cc:223-231)
       const uint2 own_se = *reinterpret_cast<const uint2 *>(gp + 4);
-      // (journal launches: the window of a board that was reset above still shows the finished game.  Its
-      // first peg has no neighbour of its colour, so nothing of the link scan below counts; only these two
-      // flags would -- and no cell of the empty board carries both, so they cannot matter either)
-      const bool fresh = !FULL && was_reset;
-      const bool own_s = !fresh && (own_se.x & pbit) != 0u, own_e = !fresh && (own_se.y & pbit) != 0u;
+      const bool own_s = (own_se.x & pbit) != 0u, own_e = (own_se.y & pbit) != 0u;
 
       // ---- SetPegAndLinks (tb.cc:501-571).  Crossing window: board columns x-3..x+1, rows
       //      y-3..y+3 of this lane's two link planes, at their byte positions ----
@@ -607,38 +480,30 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
       const bool p_e = own_e || gain_e;
       uint32_t want = (linkm && neutral) ? ((p_s ? 1u : 0u) | (p_e ? 2u : 0u)) : 0u;  // tb.cc:558-570
       // Half of all fills flag exactly one cell: the new peg's only unflagged neighbour is a peg
-      // without any other link.  Settled here on the pre-move planes (both lanes alike); a neighbour
-      // whose links lie partly outside the window goes the long way.
+      // without any other link.  Settled here on the pre-move planes (both lanes alike).
       if (want && !(neutral & (neutral - 1u)) && (!(want & 1u) || (linkm & ~ts) == neutral) &&
           (!(want & 2u) || (linkm & ~te) == neutral)) {
         const int d = __ffs((int)neutral) - 1;
         const int tx = x + (int)((twx::kDxPack >> (4 * d)) & 15u) - 2, ty = y + (int)((twx::kDyPack >> (4 * d)) & 15u) - 2;
         const int t = tx * N + ty;
-        bool seen = FULL || win_has(t >> 5);
-        const uint32_t *const gt = wq + 6 * ((seen ? t : pa) >> 5);  // links that START at t
+        const uint32_t *const gt = wq + 6 * (t >> 5);  // links that START at t
         uint32_t other = (gt[0] | gt[1] | gt[2] | gt[3]) >> (t & 31);
 #pragma unroll
         for (int e = 0; e < 4; e++) {  // links that END at t: stored at t - off[e]
           const int sx = tx - twx::kDX[e], sy = ty - twx::kDY[e];
           const bool valid = sx >= 0 && sy >= 0 && sy < N;
           const int sc2 = valid ? sx * N + sy : pa;
-          const bool here = FULL || win_has(sc2 >> 5);
-          seen = seen && here;
-          const uint32_t w = wq[6 * ((here ? sc2 : pa) >> 5) + e];
+          const uint32_t w = wq[6 * (sc2 >> 5) + e];
           other |= valid ? (w >> (sc2 & 31)) : 0u;
         }
-        if (seen && !(other & 1u)) {
-          if constexpr (FULL) lds_or(wq + 6 * (t >> 5) + (up ? 5 : 4), (want & (up ? 2u : 1u)) ? (1u << (t & 31)) : 0u);
-          // persisted by this move's journal record (or by the whole-board write of this launch)
-          fill1 = ((uint32_t)d << twx::kJFillDirShift) | ((want & 1u) ? twx::kJFillStart : 0u) |
-                  ((want & 2u) ? twx::kJFillEnd : 0u);
+        if (!(other & 1u)) {
+          lds_or(wq + 6 * (t >> 5) + (up ? 5 : 4), (want & (up ? 2u : 1u)) ? (1u << (t & 31)) : 0u);  // lower: START, upper: END
           want = 0u;
         }
       }
       pend = want;
-      if constexpr (FULL) {
-        // tb.cc:532-533: one stored bit per physical link, at its west end; lower lane links 0, 1
-        // (west end = the new peg) and 4, 5 (west end = the target), upper lane 2, 3 and 6, 7
+      {  // tb.cc:532-533: one stored bit per physical link, at its west end; lower lane links 0, 1
+         // (west end = the new peg) and 4, 5 (west end = the target), upper lane 2, 3 and 6, 7
         const uint32_t lo = linkm >> (2 * h);
         lds_or2(gp + link_lo, pbit & (uint32_t)sbit(lo, 0), pbit & (uint32_t)sbit(lo, 1));
 #pragma unroll
@@ -658,22 +523,10 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
         const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
         if (cnt_opp - (in_opp ? 1 : 0) == 0) result = 3u;
       }
-      entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
-              (gain_s ? twx::kJGainStart : 0u) | (gain_e ? twx::kJGainEnd : 0u) | (swapnow ? twx::kJSwap : 0u) |
-              (result << twx::kJResultShift) | fill1;
     }
-    // scalars (FULL: s3 = the board's dirty mask during the flood below) and this move's record, both in
-    // LDS: the flood pass of a journal launch reads them from there.  (A board that was reset in a journal
-    // launch is written whole with the scalars of the EMPTY board and its journal base: its first move is
-    // in the record, and stored scalars + records from the base on = the truth; a launch that rewrites
-    // everything stores base 0.)
-    if (!up) {
-      *reinterpret_cast<uint4 *>(sc) =
-          (was_reset && !FULL)
-              ? make_uint4(0u, jbase << twx::kJBaseShift, episode, 0u)
-              : make_uint4(counter | (move_one << 16), result | (swapped << 8) | (FULL ? 0u : jbase << twx::kJBaseShift),
-                           episode, 0u);
-    }
+    // the scalars as they stand after the move (everything is rewritten: journal base 0)
+    if (!up)
+      *reinterpret_cast<uint4 *>(sc) = make_uint4(counter | (move_one << 16), result | (swapped << 8), episode, 0u);
     wave_sync();
 
     // ---- ExploreLocalGraph (tb.cc:573-588), wave-cooperative, two boards per pass: lanes 0..31 on one
@@ -693,31 +546,7 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
       const uint32_t spend = (up && !two) ? 0u
                              : (uint32_t)(up ? __builtin_amdgcn_readlane((int)pend, s1)
                                               : __builtin_amdgcn_readlane((int)pend, s0));
-      uint32_t *fb;  // the board's whole links + flags region in LDS
-      if constexpr (FULL) {
-        fb = lds + D_REG + src * (LFB / 4);
-      } else {
-        // fetch it: lanes 0..LFP-1 of each half, one piece each (LFP <= 27); then the board's records
-        // of this period and this move's own record, one lane per record
-        fb = lds + D_FB + h * (LFB / 4);
-        const uint32_t srcoff = (uint32_t)(WG::L_ROWS + src * LFB + (bl < LFP ? bl : 0) * 16);
-        u32x4 pv;
-        __builtin_amdgcn_sched_barrier(0);
-        gload16v(pv, srcoff, tile_cur_c);
-        vm_wait_all();  // (also the next batch's rows: they have been under way since the window fetch)
-        if (bl < LFP) lwrite16v(lds0 + (uint32_t)(D_FB * 4 + h * LFB + bl * 16), pv);
-        __builtin_amdgcn_sched_barrier(0);
-        wave_sync();
-        if (bl <= jpos && bl < twx::kJournalSlots) {
-          const uint32_t sjb = (lds[RSC * 128 + src * 4 + 1] >> twx::kJBaseShift) & 15u;
-          uint32_t e = 0u;
-          if (bl == jpos) e = (uint32_t)(up ? __builtin_amdgcn_readlane((int)entry, s1) : __builtin_amdgcn_readlane((int)entry, s0));
-          else if ((uint32_t)bl >= sjb) e = lds[RJ * 128 + bl * 32 + src];
-          if (up && !two) e = 0u;
-          record_on_region<N>(fb, e);
-        }
-        wave_sync();
-      }
+      uint32_t *const fb = lds + D_REG + src * (LFB / 4);  // the board's whole links + flags region, in place
       const int sx = spa / N, sy = spa - sx * N;
       const bool ok = c < N;
       const int o = (ok ? c : 0) * N, sh = o & 31, grp = o >> 5;
@@ -729,7 +558,6 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
       uint32_t lk[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) lk[e] = col(e);
-      uint32_t dirty = 0u;  // words of the region whose flags this lane changed
 #pragma unroll
       for (int f = 0; f < 2; f++) {
         const bool en = (spend >> f) & 1u;  // uniform per half
@@ -759,27 +587,8 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
         }
         const uint32_t add = flag & ~flag0;
         if (ok && add) {
-          dirty |= 1u << grp;
           lds_or(g + off, add << sh);
-          if (sh + N > 32) {
-            lds_or(g + off + 6, add >> (32 - sh));
-            dirty |= 2u << grp;
-          }
-        }
-        wave_sync();
-      }
-      if constexpr (!FULL) {
-        // the flag words the flood changed go back as 8-byte pieces { start_i, end_i }: lane i of the half
-        // stores word i if some lane of the half marked it
-        uint32_t dm = dirty;
-#pragma unroll
-        for (int s = 1; s < 32; s <<= 1) dm |= (uint32_t)__shfl_xor((int)dm, s, 32);
-        if (kAblate & 2) dm = 0u;
-        if (bl < W && ((dm >> bl) & 1u) && !(up && !two)) {
-          const uint2 fv = *reinterpret_cast<const uint2 *>(fb + 6 * bl + 4);
-          uint32_t *const dst = reinterpret_cast<uint32_t *>(const_cast<char *>(tile_cur_c) + WG::L_ROWS + src * LFB + 24 * bl + 16);
-          __builtin_nontemporal_store(fv.x, dst);
-          __builtin_nontemporal_store(fv.y, dst + 1);
+          if (sh + N > 32) lds_or(g + off + 6, add >> (32 - sh));
         }
         wave_sync();
       }
@@ -797,42 +606,16 @@ __device__ __forceinline__ void step_window_body(char *__restrict__ state, long 
     // ---- stream back ----
     char *const tile_cur = const_cast<char *>(tile_cur_c);
     const bool wr = !(kAblate & 16);
-    if constexpr (FULL) {
-      // pegs and scalars (rows 0..RP) and every links + flags region, from LDS; the journal rows stay as
-      // they are (stale from now on)
+    // pegs and scalars (rows 0..RP) and every links + flags region, from LDS; the journal rows stay as
+    // they are (stale from now on)
 #pragma unroll
-      for (int j = 0; j < NJA; j++)
-        if (wr && 2 * j + h <= RSC)
-          tile_store<true>(reinterpret_cast<uint4 *>(tile_cur + (2 * j + h) * 512 + bl * 16), lds4[(2 * j + h) * 32 + bl]);
+    for (int j = 0; j < NJA; j++)
+      if (wr && 2 * j + h <= RSC)
+        tile_store<true>(reinterpret_cast<uint4 *>(tile_cur + (2 * j + h) * 512 + bl * 16), lds4[(2 * j + h) * 32 + bl]);
 #pragma unroll
-      for (int k = 0; k < NLF; k++)
-        if (wr && k * 64 + lane < 32 * LFP)
-          tile_store<true>(reinterpret_cast<uint4 *>(tile_cur + WG::L_ROWS + (k * 64 + lane) * 16), lds4[D_REG / 4 + k * 64 + lane]);
-    } else {
-      // this move's record: all a step normally writes -- one dword per board, one 128-byte line per tile
-      if (wr && !up)
-        tile_store_word<true>(reinterpret_cast<uint32_t *>(tile_cur + RJ * 512 + jpos * (BPW * 4)) + bl, entry);
-      if (__ballot(was_reset)) {
-        // auto-reset boards are rewritten whole: peg rows and scalars from LDS (the pegs are empty: the
-        // move is in the record), the links + flags region from the constants of the empty board
-        if (was_reset && wr) {
-#pragma unroll
-          for (int j = 0; j < NJA; j++)
-            if (2 * j + h <= RSC)
-              tile_store<true>(reinterpret_cast<uint4 *>(tile_cur + (2 * j + h) * 512 + bl * 16), lds4[(2 * j + h) * 32 + bl]);
-          uint32_t *const dst = reinterpret_cast<uint32_t *>(tile_cur + WG::L_ROWS + bl * LFB);
-#pragma unroll
-          for (int i = 0; i < W; i++)
-            if ((i & 1) == h) {
-              // (8-byte stores: links 0, 1 | links 2, 3 | START, END of word i)
-              __builtin_nontemporal_store(0u, dst + 6 * i + 0); __builtin_nontemporal_store(0u, dst + 6 * i + 1);
-              __builtin_nontemporal_store(0u, dst + 6 * i + 2); __builtin_nontemporal_store(0u, dst + 6 * i + 3);
-              __builtin_nontemporal_store(G::tab.init[twx::kPlaneStart * W + i], dst + 6 * i + 4);
-              __builtin_nontemporal_store(G::tab.init[twx::kPlaneEnd * W + i], dst + 6 * i + 5);
-            }
-        }
-      }
-    }
+    for (int k = 0; k < NLF; k++)
+      if (wr && k * 64 + lane < 32 * LFP)
+        tile_store<true>(reinterpret_cast<uint4 *>(tile_cur + WG::L_ROWS + (k * 64 + lane) * 16), lds4[D_REG / 4 + k * 64 + lane]);
     if (inb && !flush && !up) {
       if (status) {
         uint8_t st = (uint8_t)(result | (swapped << 5));
@@ -856,7 +639,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     char *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
-  step_window_body<N, true>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, tbase, nstatic);
+  step_window_full_body<N>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, tbase, nstatic);
 }
 
 #endif  // TWIXT_WINDOW_KERNEL_H_
