@@ -258,7 +258,8 @@ __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)
 
 constexpr int kFlagRandom = 1, kFlagAutoReset = 2, kFlagCompact = 4, kFlagFlush = 8, kFlagReverse = 16,
               kFlagRolling = 32,  // + bits 8..11: journal period, bits 12..27: batch stride of a wave
-              kFlagDynamic = 64;  // batches after a wave's first are drawn from the ticket counters
+              kFlagDynamic = 64,  // batches after a wave's first are drawn from the ticket counters
+              kFlagWholeTile = 128;  // split layout: this rewriting launch takes step_window_full_kernel (small batches)
 
 // dynamic batch order: one ticket counter per group of waves (blockIdx.x % kTicketGroups),
 // counters kTicketStride words apart; the bases travel as a kernel argument

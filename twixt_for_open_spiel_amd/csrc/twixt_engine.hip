@@ -138,15 +138,15 @@ hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *act
   if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
     const long nbatch = bpad / 32;
     const long grid = nbatch < (long)waves ? nbatch : (long)waves;
-    const bool full = (flags & kFlagCompact) != 0;
+    const bool full = (flags & kFlagWholeTile) != 0;
     const size_t lds_bytes = (size_t)WinGeo<N>::lds_bytes_full;
     char *st = reinterpret_cast<char *>(state);
-    if (!full) {  // journal launches: one lane per board, 64 boards per wave (twixt_window1_kernel.h)
+    if (!full) {  // journal launches, compactions, flushes: one lane per board, 64 boards per wave (twixt_window1_kernel.h)
       const long nb64 = bpad / 64;
       const long grid1 = nb64 < (long)waves ? nb64 : (long)waves;
       hipLaunchKernelGGL((step_window1_kernel<N>), dim3((unsigned)grid1), dim3(kWave), (size_t)Win1Geo<N>::lds_bytes, s, st, bpad,
                          batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
-    } else {  // compactions, flushes: two lanes per board, whole tiles (twixt_window_kernel.h)
+    } else {  // small batches: every step rewrites whole tiles, two lanes per board (twixt_window_kernel.h)
       hipLaunchKernelGGL((step_window_full_kernel<N>), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, st, bpad, batch,
                          actions, actions_out, status, seed, first_id, flags, jpos, ticket, ticket_base, nstatic);
     }
@@ -329,6 +329,7 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     // per step at N=24, B=16,384.)
     flags |= kFlagCompact;
     jarg = 0;
+    if (e->d.lay != 0 && whole_step && e->small_rewrite && (e->d.bpad / 64) * 4 <= (long)e->waves_win) flags |= kFlagWholeTile;
   } else if (!e->rolling && e->jpos == e->period - 1) {
     flags |= kFlagCompact;
   }
@@ -339,8 +340,8 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
     // whole-batch launches of the big boards: the two-lanes-per-board kernel
     const bool use_win = e->d.lay != 0 && !ids && rsteps == 1;
     const bool use_pair = use_win || (e->pair && !ids && rsteps == 1 && !(flags & kFlagRolling));
-    int bpw = (use_pair && !(use_win && e->win_one_lane && !(flags & kFlagCompact))) ? 32 : kWave;  // boards per wave
-    const int waves = use_win ? ((flags & kFlagCompact) ? e->waves_win_full : e->waves_win) : use_pair ? e->waves_pair : e->waves;
+    int bpw = (use_pair && !(use_win && !(flags & kFlagWholeTile))) ? 32 : kWave;  // boards per wave
+    const int waves = use_win ? ((flags & kFlagWholeTile) ? e->waves_win_full : e->waves_win) : use_pair ? e->waves_pair : e->waves;
     // a short list of boards is spread over many waves (rows per wave: a power of two, at least 4,
     // while that still fills four waves per CU): see step_body
     if (ids)

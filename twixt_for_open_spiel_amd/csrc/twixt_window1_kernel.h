@@ -77,7 +77,6 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   constexpr int BPW = 64;
   constexpr int NS = twx::kJournalSlots - 1;  // records a journal launch may have to replay
   constexpr uint32_t kColMask = (1u << N) - 1u;
-  constexpr int kTrash = 4 * NPC;             // dword of a window's padding piece
   static_assert(twx::kJournalChunks == 2 && W <= 32 && LFP <= 32 && WSTR == NPC + 1 && (NPC & 1) == 0, "layout");
   static_assert(RSC * 512 - 2048 <= 4095 && RJ * 512 + 7 * 128 - 2048 <= 4095, "row offsets fit the load immediates");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -87,6 +86,8 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   const int lane = threadIdx.x;
   const int th = lane >> 5, q = lane & 31;  // tile of the batch, board slot of the tile
   const bool random = (flags & kFlagRandom) != 0;
+  const bool compact = (flags & kFlagCompact) != 0;  // this launch also writes peg rows and scalars back (journal base 0)
+  const bool flush = (flags & kFlagFlush) != 0;      // ... and makes no move
   const long nbatch = bpad / BPW;
 
   const bool dyn = (flags & kFlagDynamic) != 0;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   bool c_valid = false;
   long c_idx = 0;
   int c_a = -1, c_pa = 0;
-  uint32_t c_counter = 0, c_move_one = 0, c_result = 0, c_swapped = 0, c_cand = 0;
+  uint32_t c_counter = 0, c_move_one = 0, c_result = 0, c_swapped = 0, c_cand = 0, c_episode = 0;
   uint32_t c_jr[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) c_jr[s] = 0u;
@@ -177,7 +178,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
     const long row = batch_of(have ? idx : 0) * BPW + lane;  // = board: whole-batch launches only
     const bool inb = have && row < batch;
     int a_ext = -1;
-    if (!random && have) {  // external actions (twx_step): loaded, and waited for, before anything untracked is issued
+    if (!random && !flush && have) {  // external actions (twx_step): loaded, and waited for, before anything untracked is issued
       if (inb) a_ext = actions[row];
       asm volatile("" : "+v"(a_ext));
     }
@@ -216,7 +217,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
 
     // ---- 2. choose the moves of batch idx ----
     int n_a = -1, n_pa = 0;
-    uint32_t n_counter = 0, n_move_one = 0, n_result = 0, n_swapped = 0, n_cand = 0, n_bits = 0;
+    uint32_t n_counter = 0, n_move_one = 0, n_result = 0, n_swapped = 0, n_cand = 0, n_bits = 0, n_episode = 0;
     if (have) {
       const char *const tile_cur = tile_of(idx);
       __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +293,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       STAMP(3);  // legal mask
 
       int a = -1;
-      bool act = inb && open;
+      bool act = inb && open && !flush;
       bool illegal = false;
       if (random) {
         act = act && cnt > 0;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
         }
         a = wsel * 32 + select_bit(msel, k - base);
         if (!act) a = -1;
-      } else {
+      } else if (!flush) {
         a = a_ext;
         bool legal = false;
         if (a >= 0 && a < N * N) {
@@ -350,6 +351,17 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       // would this move take the opponent's last free cell (tb.cc:202-206)?
       const bool in_opp = player ? (x >= 1 && x <= N - 2) : (y >= 1 && y <= N - 2);
       const bool wdraw = counter + 1u > 2u && cnt_opp - (in_opp ? 1 : 0) == 0;
+      if (compact) {
+        // ---- a compaction: the pegs as they stand after this move go back to their rows (the scalars follow from
+        //      the apply phase, which knows the result).  Regions are always current in HBM: nothing else to write ----
+        if (swapnow) lds_and(pegw(a >> 5), ~(1u << (a & 31)));            // tb.cc:450-455: undo red's first peg
+        if (act) lds_or(pegw(pa >> 5) + player, 1u << (pa & 31));         // tb.cc:507-508
+        wave_sync();
+        char *const tw = const_cast<char *>(tile_cur) + my_tile + q * 16;
+#pragma unroll
+        for (int r = 0; r < RP; r++)
+          tile_store<true>(reinterpret_cast<uint4 *>(tw + r * 512), *reinterpret_cast<const uint4 *>(pegme + r * 256));
+      }
       // ---- the window: ten pieces of this board's region, fetched by the lane itself ----
       const uint32_t voff_w = my_tile + (uint32_t)(WG::L_ROWS + q * LFB + 16 * window_piece0(x));
       __builtin_amdgcn_sched_barrier(0);
@@ -359,7 +371,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       });
       __builtin_amdgcn_sched_barrier(0);
       n_a = a; n_pa = pa;
-      n_counter = counter; n_move_one = move_one; n_result = result; n_swapped = swapped; n_cand = cand;
+      n_counter = counter; n_move_one = move_one; n_result = result; n_swapped = swapped; n_cand = cand; n_episode = episode;
       n_bits = (act ? 1u : 0u) | (illegal ? 2u : 0u) | (was_reset ? 4u : 0u) | (swapnow ? 8u : 0u) | (inb ? 16u : 0u) |
                (wdraw ? 32u : 0u);
     }
@@ -367,48 +379,15 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
 
     // ---- 3. apply the moves of the carried batch on its windows ----
     uint32_t entry = 0, c_pend = 0;  // this move's record; bit0 / bit1: flood START / END from the new peg
-    uint32_t o_result = c_result, o_swapped = c_swapped;
+    uint32_t o_result = c_result, o_swapped = c_swapped, o_counter = c_counter, o_move_one = c_move_one;
     if (c_valid) {
       const bool act = (c_bits & 1u) != 0u, fresh = (c_bits & 4u) != 0u, swapnow = (c_bits & 8u) != 0u;
       const int pa = c_pa;
       const int x = pa / N, y = pa - x * N;
       const int player = (int)(c_counter & 1u);
       const int piece0 = window_piece0(x);
-      // dword of plane p (2..7 -> 0..5) of word w inside this board's window area, or the padding piece
-      auto rel = [&](int w, int p) -> int {
-        const uint32_t r = (uint32_t)(6 * w + p - 4 * piece0);
-        return (int)(r < (uint32_t)kTrash ? r : (uint32_t)kTrash);
-      };
       auto win_has = [&](int w) -> bool { return (uint32_t)(24 * w - 16 * piece0) <= (uint32_t)(16 * NPC - 24); };
-      // the records' link / flag bits: straight-line ORs, what falls outside the window goes to the padding
-#pragma unroll
-      for (int s = 0; s < NS; s++) {
-        if (s < jpos) {  // wave-uniform
-          const uint32_t e = c_jr[s];
-          const uint32_t valid = (uint32_t)((int32_t)e >> 31);
-          const int cell = (int)(e & 1023u);
-          const uint32_t bit = (1u << (cell & 31)) & valid;
-          // (dword pairs: even offsets, so a pair is inside the window or in the padding as a whole)
-          lds_or2(winme + rel(cell >> 5, 0), bit & (uint32_t)sbit(e, 11), bit & (uint32_t)sbit(e, 12));
-          lds_or2(winme + rel(cell >> 5, 2), bit & (uint32_t)sbit(e, 13), bit & (uint32_t)sbit(e, 14));
-          lds_or2(winme + rel(cell >> 5, 4), bit & (uint32_t)sbit(e, 19), bit & (uint32_t)sbit(e, 20));
-#pragma unroll
-          for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
-            const uint32_t on = (uint32_t)sbit(e, 11 + d) & valid;
-            const int tc = cell + (int)((uint32_t)(twx::kDX[d] * N + twx::kDY[d]) & on);
-            lds_or(winme + rel(tc >> 5, d - 4), (1u << (tc & 31)) & on);
-          }
-          if (__ballot((e & (twx::kJFillStart | twx::kJFillEnd)) != 0u)) {  // the single neighbour a fill flagged
-            const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
-            const uint32_t on_s = (uint32_t)sbit(e, 27) & valid, on_e = (uint32_t)sbit(e, 28) & valid;
-            const int tf = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
-            const int t = (on_s | on_e) ? tf : cell;
-            lds_or2(winme + rel(t >> 5, 4), (1u << (t & 31)) & on_s, (1u << (t & 31)) & on_e);
-          }
-        }
-      }
-      wave_sync();
-      STAMP(5);  // region replay
+      STAMP(5);  // (no replay here: the regions in HBM are always current)
       uint32_t pend = 0, fill1 = 0;
       uint32_t counter2 = c_counter, move_one2 = c_move_one, result2 = c_result, swapped2 = c_swapped;
       if (act) {
@@ -488,7 +467,6 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
             want = 0u;
           }
         }
-        (void)pbit;
         pend = want;
         if (counter2 == 0u) move_one2 = (uint32_t)pa;  // tb.cc:485-488
         counter2 += 1u;
@@ -498,9 +476,45 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
         entry = twx::kJValid | (uint32_t)pa | ((uint32_t)player << 10) | (linkm << 11) |
                 (gain_s ? twx::kJGainStart : 0u) | (gain_e ? twx::kJGainEnd : 0u) | (swapnow ? twx::kJSwap : 0u) |
                 (result2 << twx::kJResultShift) | fill1;
+        // ---- the region words this move changes (tb.cc:532-546): ORed into the window, then stored from there --
+        //      8-byte pairs / single dwords through L2, where the window's lines still are (a board's region in
+        //      HBM is current after every step; the record above keeps carrying the same bits for the kernels that
+        //      replay whole boards).  One stored bit per physical link, at its west end. ----
+        uint32_t *const gp = wq + 6 * (pa >> 5);
+        const uint32_t b01 = linkm & 3u, b23 = linkm & 12u, bse = (gain_s ? 1u : 0u) | (gain_e ? 2u : 0u);
+        lds_or2(gp + 0, (linkm & 1u) ? pbit : 0u, (linkm & 2u) ? pbit : 0u);
+        lds_or2(gp + 2, (linkm & 4u) ? pbit : 0u, (linkm & 8u) ? pbit : 0u);
+        lds_or2(gp + 4, gain_s ? pbit : 0u, gain_e ? pbit : 0u);
+        int tcell[4];
+#pragma unroll
+        for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
+          const bool on = (linkm >> d) & 1u;
+          tcell[d - 4] = on ? pa + twx::kDX[d] * N + twx::kDY[d] : pa;
+          lds_or(wq + 6 * (tcell[d - 4] >> 5) + (d - 4), on ? (1u << (tcell[d - 4] & 31)) : 0u);
+        }
+        int tfill = pa;
+        if (fill1) {  // the single neighbour the shortcut flagged
+          const int fd = (int)((fill1 >> twx::kJFillDirShift) & 7u);
+          tfill = pa + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
+          lds_or2(wq + 6 * (tfill >> 5) + 4, (fill1 & twx::kJFillStart) ? (1u << (tfill & 31)) : 0u,
+                  (fill1 & twx::kJFillEnd) ? (1u << (tfill & 31)) : 0u);
+        }
+        wave_sync();
+        char *const rb = tile_of(c_idx) + my_tile + (WG::L_ROWS + q * LFB);  // this board's region in HBM
+        if (b01 | b23) {  // (the four link words of the cell's word as one 16-byte piece)
+          const uint2 la = *reinterpret_cast<const uint2 *>(gp + 0), lb = *reinterpret_cast<const uint2 *>(gp + 2);
+          uint32_t *const d4 = reinterpret_cast<uint32_t *>(rb + 24 * (pa >> 5));
+          d4[0] = la.x; d4[1] = la.y; d4[2] = lb.x; d4[3] = lb.y;
+        }
+        if (bse) *reinterpret_cast<uint2 *>(rb + 24 * (pa >> 5) + 16) = *reinterpret_cast<const uint2 *>(gp + 4);
+#pragma unroll
+        for (int d = 4; d < 8; d++)
+          if ((linkm >> d) & 1u)
+            *reinterpret_cast<uint32_t *>(rb + 24 * (tcell[d - 4] >> 5) + 4 * (d - 4)) = wq[6 * (tcell[d - 4] >> 5) + (d - 4)];
+        if (fill1)
+          *reinterpret_cast<uint2 *>(rb + 24 * (tfill >> 5) + 16) = *reinterpret_cast<const uint2 *>(wq + 6 * (tfill >> 5) + 4);
       }
-      o_result = result2; o_swapped = swapped2;
-      (void)move_one2;
+      o_result = result2; o_swapped = swapped2; o_counter = counter2; o_move_one = move_one2;
       c_pend = pend;
     }
     STAMP(6);  // link scan, result, record
@@ -524,19 +538,10 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
     //      boards' records of this period and the move itself replayed on them by eight lanes at once, the flood,
     //      the flag words that changed stored as 8-byte pieces. ----
     auto region_of = [&](int s) -> uint32_t { return (uint32_t)(s >> 5) * (uint32_t)WG::TILE + (uint32_t)(WG::L_ROWS + (s & 31) * LFB); };
-    auto flood_notes = [&](uint32_t &notes, auto half, int sq) {  // the notes of the board in lane sq into half-wave `half`
+    auto flood_notes = [&](uint32_t &notes, auto half, int sq) {  // cell and pending flags of the board in lane sq -> half-wave `half`
       constexpr int Q = decltype(half)::value;
-      static_for<0, 10>([&](auto it) {
-        constexpr int JJ = decltype(it)::value;
-        uint32_t mine;
-        if constexpr (JJ < twx::kJournalSlots) {
-          const uint32_t r = JJ < NS ? c_jr[JJ < NS ? JJ : 0] : 0u;
-          mine = JJ < jpos ? r : (JJ == jpos ? entry : 0u);
-        } else {
-          mine = JJ == 8 ? (uint32_t)c_pa : c_pend;
-        }
-        set_lane<32 * Q + JJ>(notes, __builtin_amdgcn_readlane((int)mine, sq));
-      });
+      set_lane<32 * Q + 8>(notes, __builtin_amdgcn_readlane(c_pa, sq));
+      set_lane<32 * Q + 9>(notes, __builtin_amdgcn_readlane((int)c_pend, sq));
     };
     using Half0 = std::integral_constant<int, 0>;
     using Half1 = std::integral_constant<int, 1>;
@@ -548,9 +553,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       const bool idle = up && !two;  // one board only: the upper half has nothing to do
       const int spa = up ? __builtin_amdgcn_readlane((int)notes, 40) : __builtin_amdgcn_readlane((int)notes, 8);
       const uint32_t spend = idle ? 0u : (uint32_t)(up ? __builtin_amdgcn_readlane((int)notes, 41) : __builtin_amdgcn_readlane((int)notes, 9));
-      uint32_t *const fb = fbase + th * (LFB / 4);
-      if (q < twx::kJournalSlots && !idle) record_on_region<N>(fb, notes);
-      wave_sync();
+      uint32_t *const fb = fbase + th * (LFB / 4);  // (the region as it is in HBM: current, this move included)
       const int sx = spa / N, sy = spa - sx * N;
       const bool ok = c < N;
       const int o = (ok ? c : 0) * N, sh = o & 31, grp = o >> 5;
@@ -676,9 +679,13 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       // this move's record: all a step normally writes -- one dword per board, one 128-byte line per tile
       char *const tile_c = tile_of(c_idx);
       const long crow = batch_of(c_idx) * BPW + lane;
-      if (!(kAblate & 16))
+      if (compact) {  // the scalars as they stand after the move (the rows went back in the select phase); base 0
+        tile_store<true>(reinterpret_cast<uint4 *>(tile_c + my_tile + RSC * 512 + q * 16),
+                         make_uint4(o_counter | (o_move_one << 16), o_result | (o_swapped << 8), c_episode, 0u));
+      } else if (!(kAblate & 16)) {
         tile_store_word<true>(reinterpret_cast<uint32_t *>(tile_c + my_tile + RJ * 512 + jpos * 128) + q, entry);
-      if (c_bits & 16u) {
+      }
+      if ((c_bits & 16u) && !flush) {
         if (status) {
           uint8_t st = (uint8_t)(o_result | (o_swapped << 5));
           if (c_bits & 2u) st |= TWX_ST_ILLEGAL;
@@ -695,7 +702,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
     c_valid = have;
     c_idx = uniform_long(idx);
     c_a = n_a; c_pa = n_pa; c_counter = n_counter; c_move_one = n_move_one; c_result = n_result; c_swapped = n_swapped;
-    c_cand = n_cand; c_bits = n_bits;
+    c_cand = n_cand; c_bits = n_bits; c_episode = n_episode;
 #pragma unroll
     for (int s = 0; s < NS; s++) c_jr[s] = jr[s];
     if (have) {  // (kept in scalar registers: the loop and its phases branch on them)
