@@ -35,6 +35,10 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                     # same guide: measured float4-copy ceiling
 MIN_TIMED_MS = 50.0                       # the K-step block is repeated until this much GPU time
 TRAFFIC_FILE = os.path.join("profiles", "traffic_step_kernel_n24.json")
+# Region words a move stores on the big boards, bytes requested per env step (mean over random N=24 games:
+# about one link per move -- 16 B when the new peg is a link's west end, 4 B at the other peg otherwise --
+# and 8 B of flags for one move in eight): a model constant, the PMC write count is the measurement.
+REGION_UPDATE_BYTES = 10.0
 
 
 def journal_period(n):
@@ -53,15 +57,11 @@ def split_layout(n):
 
 
 def step_kernel_name(n):
-    """The kernel most whole-batch step launches run at board size n (twixt_engine.hip run_step):
-    the journal launches of the big boards; their compactions run compaction_kernel_name(n)."""
+    """The kernel every whole-batch step launch runs at board size n (twixt_engine.hip run_step); on the big
+    boards journal launches and compactions are the same kernel (a compaction also stores pegs and scalars)."""
     if split_layout(n):
         return "step_window1_kernel<%d>" % n
     return "step_kernel64_small<%d, false>" % n
-
-
-def compaction_kernel_name(n):
-    return "step_window_full_kernel<%d>" % n if split_layout(n) else step_kernel_name(n)
 
 
 def window_geometry(n):
@@ -75,18 +75,20 @@ def window_geometry(n):
     return {"W": w, "RP": rp, "LFB": lfb, "NW": nw, "NPC": npc}
 
 
-def design_bytes_split(n, multi_cell_fills=0.028):
+def design_bytes_split(n, multi_cell_fills=0.028, region_update=REGION_UPDATE_BYTES):
     """Bytes the windowed step requests per env step by construction, big boards.
-    Journal launch with j records: pegs (8 W) + scalars (16) + the records (4 j) + the window (16 NPC) +
-    the whole region of the boards with a multi-cell fill; it writes its record (4 B).  The compaction
-    reads the whole tile (pegs, scalars, P-1 records, regions) and writes pegs, scalars and regions.
-    Returns (per step averaged over a period, journal launch mean, compaction launch).  The memory side
-    moves whole 128-byte lines: a window of 160 B at a 16-byte offset touches 2.1 of them on average, so the
-    PMC traffic of a journal launch is above this request count."""
+    A launch with j records to replay reads pegs (16 RP) + scalars (16) + the records (4 j) + the window
+    (16 NPC) + the whole region of the boards with a multi-cell fill, and writes the region words its move
+    changes (`region_update`: the cell's link words, flag pairs, the far ends' link words -- a mean over random
+    games) plus its record (4 B); the P-th launch of a period, the compaction, writes pegs and scalars instead
+    of a record.  Returns (per step averaged over a period, journal launch mean, compaction launch).  The
+    memory side moves whole 128-byte lines: a window of 160 B at a 16-byte offset touches 2.1 of them on
+    average and a region update dirties 32-byte sectors, so the PMC traffic is above this request count."""
     g, p = window_geometry(n), journal_period(n)
-    rows = 8 * g["W"] + 16
-    journal = [rows + 4 * j + 16 * g["NPC"] + multi_cell_fills * g["LFB"] + 4 for j in range(p - 1)]
-    compaction = (rows + 4 * (p - 1) + g["LFB"]) + (rows + g["LFB"])
+    rows = 16 * g["RP"] + 16
+    reads = [rows + 4 * j + 16 * g["NPC"] + multi_cell_fills * g["LFB"] for j in range(p)]
+    journal = [r + region_update + 4 for r in reads[:p - 1]]
+    compaction = reads[p - 1] + region_update + rows
     jmean = sum(journal) / max(1, len(journal))
     return (sum(journal) + compaction) / p, jmean, compaction
 
@@ -479,18 +481,9 @@ def main(argv=None):
         traffic, traffic_src = (None, {"rejected": "dry run"}) if args.dry_run else measured_traffic(n, B)
         moved = traffic if traffic is not None else db * B  # bytes per launch (mean over a period) really moved
         achieved_all = moved / (kernel_ms * 1e-3) / 1e9
-        # the dominant kernel: the journal launches (P-1 of P); its own bytes and its own launch time
-        pk = (traffic_src or {}).get("per_kernel") or {}
-        dom, comp_name = step_kernel_name(n), compaction_kernel_name(n)
-        if journal_ms is not None and split_layout(n):
-            dom_bytes = pk.get(dom, {}).get("hbm_bytes_per_launch") if traffic is not None else None
-            dom_traffic = dom_bytes
-            if dom_bytes is None:
-                dom_bytes = design_bytes_split(n)[1] * B
-            dom_ms = journal_ms
-        else:
-            dom_bytes, dom_traffic, dom_ms = moved, traffic, kernel_ms
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # one kernel runs every launch (journal launches and compactions alike): its mean bytes, its mean time
+        dom = step_kernel_name(n)
+        achieved = achieved_all
         out = {
             "metric": "env steps/sec at board_size=%d, batch=%d per GPU, random-action rollouts" % (n, B),
             "value": agg["value"],
@@ -517,27 +510,25 @@ def main(argv=None):
                                  "value = all env steps / slowest rank's summed block time" % (blocks, K),
                        "result_hist_rank0": hist, "dry_run": bool(args.dry_run)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": dom_traffic,
-                         "basis": ("bytes moved per launch of this kernel by PMC (traffic) / its mean launch time" if dom_traffic is not None else
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "basis": ("bytes moved per launch of this kernel by PMC (traffic) / its mean launch time" if traffic is not None else
                                    "design byte model x boards / kernel time (no PMC measurement of this build and "
                                    "workload is committed: traffic is null)"),
                          "traffic_source": traffic_src,
                          "peak_measured_copy": HBM_COPY_GBS,
                          "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                          "kernel": dom,
-                         "kernel_ms": dom_ms,
-                         "share_of_launches": (journal_period(n) - 1.0) / journal_period(n) if split_layout(n) else 1.0,
-                         "all_launches": {"kernels": [dom, comp_name] if split_layout(n) else [dom],
-                                          "mean_launch_ms": kernel_ms, "hbm_bytes_per_launch_mean": moved,
-                                          "achieved_GBps": achieved_all, "frac": achieved_all / HBM_PEAK_GBS,
-                                          "note": "HIP events over the timed region, journal launches and compactions alike"},
-                         "compaction": ({"kernel": comp_name, "kernel_ms": compaction_ms,
-                                         "traffic": pk.get(comp_name, {}).get("hbm_bytes_per_launch") if traffic is not None else None,
-                                         "model_bytes_per_launch": design_bytes_split(n)[2] * B}
-                                        if split_layout(n) and compaction_ms is not None else None),
+                         "kernel_ms": kernel_ms,
+                         "kernel_ms_note": "HIP events over the timed region / launches (journal launches and compactions alike)",
+                         "launch_classes": ({"journal_launch_ms": journal_ms, "compaction_launch_ms": compaction_ms,
+                                             "journal_period": journal_period(n),
+                                             "model_bytes_per_board": {"journal_launch": design_bytes_split(n)[1],
+                                                                       "compaction": design_bytes_split(n)[2]}
+                                             if split_layout(n) else None,
+                                             "note": "one HIP event per launch, outside the timed region"}
+                                            if journal_ms is not None else None),
                          "design_model_bytes_per_env_step": db,
                          "traffic_over_design_model": (traffic / B / db) if traffic is not None else None,
-                         "journal_launch_model_bytes_per_board": design_bytes_split(n)[1] if split_layout(n) else None,
                          "algorithmic_bytes_per_env_step": ab,
                          "algorithmic_equivalent_GBps": ab * B / (kernel_ms * 1e-3) / 1e9,  # (over all launches)
                          "note": "frac = bytes really moved / kernel time / 8 TB/s, so it cannot exceed 1.  "

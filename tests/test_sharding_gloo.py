@@ -133,18 +133,19 @@ def test_roofline_traffic_is_tied_to_the_build(tmp_path, monkeypatch):
 
 def test_design_byte_model():
     import bench
-    # N=24 (split layout, windowed step), period 8: a journal launch with j records requests pegs + scalars
-    # (160 B), the records (4 j), the window (10 pieces of 16 B), 2.8 % of a whole region (432 B) for the
-    # multi-cell fills, and writes its record; the compaction reads the whole tile and writes pegs, scalars, region
+    # N=24 (split layout, windowed step), period 8: a launch with j records requests pegs + scalars (160 B), the
+    # records (4 j), the window (10 pieces of 16 B), 2.8 % of a whole region (432 B) for the multi-cell fills, and
+    # writes the region words of its move (a mean) and its record; the compaction writes pegs and scalars instead
     per_step, journal, compaction = bench.design_bytes_split(24)
-    assert abs(journal - (160 + 4 * 3 + 160 + 0.028 * 432 + 4)) < 1e-9 and compaction == (160 + 28 + 432) + (160 + 432)
+    upd = bench.REGION_UPDATE_BYTES
+    assert abs(journal - (160 + 4 * 3 + 160 + 0.028 * 432 + upd + 4)) < 1e-9
+    assert abs(compaction - (160 + 4 * 7 + 160 + 0.028 * 432 + upd + 160)) < 1e-9
     assert abs(per_step - (7 * journal + compaction) / 8) < 1e-9 and bench.design_bytes(24) == per_step
     assert bench.window_geometry(24) == {"W": 18, "RP": 9, "LFB": 432, "NW": 6, "NPC": 10}
     assert bench.window_geometry(19)["NPC"] == 8 and bench.window_geometry(20)["LFB"] == 320
     assert bench.design_bytes(8) == 2 * 80 and bench.journal_period(9) == 1        # no journal: read + write the board
     assert [bench.journal_period(n) for n in (10, 12, 13, 17, 18, 24)] == [2, 2, 4, 4, 8, 8]
     assert bench.step_kernel_name(24) == "step_window1_kernel<24>" and "small" in bench.step_kernel_name(12)
-    assert bench.compaction_kernel_name(24) == "step_window_full_kernel<24>"
     assert bench.algo_bytes(24) == 1320 and bench.algo_bytes(12) == 348 and bench.algo_bytes(8) == 168
 
 

@@ -22,6 +22,12 @@ buf = (C.c_ulonglong * 16)()
 names = ["loop/prev-store issue", "LDS fill + prefetch issue", "reset/replay", "legal mask", "select",
          "apply", "flood", "wait prefetch", "status store + loop end", "fixed stores", "dirty chunk stores",
          "reset lanes / compaction stores", "flood: pass setup", "flood: iterations", "flood: write-back"]
+if os.environ.get("TWX_WINDOW", "1") != "0" and os.environ.get("TWX_PAIR", "1") != "0":
+    # step_window1_kernel's STAMP(i) sites (twixt_window1_kernel.h), 64 boards per wave-step
+    names = ["loop end of the previous iteration", "pegs and windows -> LDS", "row prefetch, scalars, reset, replay",
+             "legal mask", "move, neighbours, window fetch issue", "(nothing)", "link scan, result, record",
+             "wait for rows and windows", "ticket, waiting flood passes", "new fills: notes, requests, passes",
+             "record and status stores", "-", "-", "-", "-"]
 
 
 def run(k):
@@ -42,7 +48,7 @@ for _ in range(R):
     compact = [x + y for x, y in zip(compact, run(1))]
 for title, acc, launches in (("journal launches", normal, 7 * R), ("compaction launches", compact, R)):
     tot = sum(acc)
-    wavesteps = launches * (B // (32 if os.environ.get('TWX_PAIR', '1') != '0' else 64))
+    wavesteps = launches * (B // (64 if (os.environ.get('TWX_PAIR', '1') == '0' or os.environ.get('TWX_WINDOW', '1') != '0') else 32))
     print("--- %s ---" % title)
     for i, nm in enumerate(names):
         print("%-32s %9.1f cycles/wave-step  %5.1f %%" % (nm, acc[i] / wavesteps, 100.0 * acc[i] / tot))

@@ -1,5 +1,5 @@
-// twixt_window1_kernel.h -- step_window1_kernel<N>: the journal launches of the big boards (N >= 19) on the SPLIT
-// layout, ONE LANE PER BOARD, 64 boards per wave, software-pipelined.
+// twixt_window1_kernel.h -- step_window1_kernel<N>: the whole-batch step of the big boards (N >= 19) on the SPLIT
+// layout (journal launches, compactions and flushes), ONE LANE PER BOARD, 64 boards per wave, software-pipelined.
 // Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
 #ifndef TWIXT_WINDOW1_KERNEL_H_
 #define TWIXT_WINDOW1_KERNEL_H_
@@ -26,7 +26,12 @@
 // windows, then applies the moves of batch k.  Multi-cell flood fills (tb.cc:573-588) wait, two boards to a
 // pass (one per half-wave, lane = board column), in two pass slots whose regions are requested an iteration
 // ahead; only a fifth and sixth pending fill of one iteration is flooded on the spot.
-// Compactions and flushes stay with step_window_full_kernel (two lanes per board, whole tiles).
+// A board's links + flags region is kept CURRENT in HBM: a move's changed region words are stored by the launch
+// that makes it (through L2, where the window's lines still are), so no launch replays records on a region and a
+// compaction (every eighth launch) or flush is this same kernel storing the peg rows and scalars as well.
+// (Measured without any journal -- peg chunk and scalars stored every step: 0.1327 against 0.1236 ms per step;
+// two scattered 16-byte stores per board cost more than one record in a full line and a compaction in eight.)
+// Batches too small to fill the chip rewrite whole tiles instead: step_window_full_kernel.
 //
 // Reference lines: Board::ApplyAction tb.cc:457-499, SetPegAndLinks tb.cc:501-571, ExploreLocalGraph
 // tb.cc:573-588, UpdateResult tb.cc:192-207, LegalActions / DoApplyAction tw.h:86-104, Board::Board tb.cc:168-276.
@@ -276,6 +281,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       const bool count_opp = __ballot(counter + 1u >= (uint32_t)(N * (N - 2))) != 0ull;
       int cnt = 0, cnt_opp = 1 << 20;  // "plenty": no draw
       if (count_opp) cnt_opp = 0;
+      const uint32_t not_swap = (counter == 1u) ? 0u : 0xffffffffu;
 #pragma unroll
       for (int r = 0; r < RP; r++) {
         const uint4 rb = *reinterpret_cast<const uint4 *>(pegme + r * 256);
@@ -283,11 +289,11 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
         for (int k = 0; k < 2; k++) {
           const int w = 2 * r + k;
           const uint32_t reg_r = w < W ? G::tab.region[0][w < W ? w : 0] : 0u, reg_b = w < W ? G::tab.region[1][w < W ? w : 0] : 0u;
-          const uint32_t red = k ? rb.z : rb.x, blue = k ? rb.w : rb.y, occ = red | blue;
-          // (move 1, blue to move: red's first peg stays legal for blue -- the swap)
-          m[w] = (player ? reg_b : reg_r) & ~((counter == 1u) ? blue : occ);
+          const uint32_t red = k ? rb.z : rb.x, blue = k ? rb.w : rb.y;
+          // (move 1, blue to move: red's first peg stays legal for blue -- the swap; blue has no peg yet)
+          m[w] = (player ? reg_b : reg_r) & ~((red & not_swap) | blue);
           cnt += __popc(m[w]);
-          if (count_opp) cnt_opp += __popc((player ? reg_r : reg_b) & ~occ);
+          if (count_opp) cnt_opp += __popc((player ? reg_r : reg_b) & ~(red | blue));
         }
       }
       STAMP(3);  // legal mask
@@ -299,15 +305,18 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
         act = act && cnt > 0;
         const uint32_t hsh = twx::policy_hash(seed, first_id + (uint32_t)row, episode, counter);
         const int k = (int)__umulhi(hsh, (uint32_t)cnt);
-        int cum = 0, wsel = 0, base = 0;
+        int cum = __popc(m[0]), wsel = 0, base = 0;
         uint32_t msel = m[0];
 #pragma unroll
-        for (int i = 0; i < 2 * RP; i++) {  // last word whose prefix count is <= k
+        for (int i = 1; i < 2 * RP; i++) {  // last word whose prefix count is <= k
+          // (one compare in vcc per word, consumed on the spot: left to itself the scheduler hoists all the
+          // compares and parks their masks in eighteen SGPR pairs it has to spill for)
           const bool ge = k >= cum;
-          wsel = ge ? i : wsel;
+          wsel += ge ? 1 : 0;
           msel = ge ? m[i] : msel;
           base = ge ? cum : base;
           cum += __popc(m[i]);
+          __builtin_amdgcn_sched_barrier(0);
         }
         a = wsel * 32 + select_bit(msel, k - base);
         if (!act) a = -1;
@@ -362,13 +371,18 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
         for (int r = 0; r < RP; r++)
           tile_store<true>(reinterpret_cast<uint4 *>(tw + r * 512), *reinterpret_cast<const uint4 *>(pegme + r * 256));
       }
-      // ---- the window: ten pieces of this board's region, fetched by the lane itself ----
+      // ---- the window: ten pieces of this board's region, fetched by the lane itself -- when the move can make a
+      //      link at all.  A peg without a neighbour of its colour a knight's move away (3 moves in 10 of a random
+      //      game) links nothing, gains no flag and changes no region word (tb.cc:517: the scan finds nothing):
+      //      its lane fetches nothing and the apply phase ignores what its window holds ----
       const uint32_t voff_w = my_tile + (uint32_t)(WG::L_ROWS + q * LFB + 16 * window_piece0(x));
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NPC>([&](auto pt) {
-        constexpr int P = decltype(pt)::value;
-        gload16iv<P * 16>(wv[P], voff_w, tile_cur);
-      });
+      if (act && cand != 0u) {
+        static_for<0, NPC>([&](auto pt) {
+          constexpr int P = decltype(pt)::value;
+          gload16iv<P * 16>(wv[P], voff_w, tile_cur);
+        });
+      }
       __builtin_amdgcn_sched_barrier(0);
       n_a = a; n_pa = pa;
       n_counter = counter; n_move_one = move_one; n_result = result; n_swapped = swapped; n_cand = cand; n_episode = episode;
@@ -381,7 +395,8 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
     uint32_t entry = 0, c_pend = 0;  // this move's record; bit0 / bit1: flood START / END from the new peg
     uint32_t o_result = c_result, o_swapped = c_swapped, o_counter = c_counter, o_move_one = c_move_one;
     if (c_valid) {
-      const bool act = (c_bits & 1u) != 0u, fresh = (c_bits & 4u) != 0u, swapnow = (c_bits & 8u) != 0u;
+      // (fresh: the window does not show this board -- reset in its select phase, or not fetched at all)
+      const bool act = (c_bits & 1u) != 0u, fresh = (c_bits & 4u) != 0u || c_cand == 0u, swapnow = (c_bits & 8u) != 0u;
       const int pa = c_pa;
       const int x = pa / N, y = pa - x * N;
       const int player = (int)(c_counter & 1u);
