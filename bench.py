@@ -39,6 +39,9 @@ TRAFFIC_FILE = os.path.join("profiles", "traffic_step_kernel_n24.json")
 # about one link per move -- 16 B when the new peg is a link's west end, 4 B at the other peg otherwise --
 # and 8 B of flags for one move in eight): a model constant, the PMC write count is the measurement.
 REGION_UPDATE_BYTES = 10.0
+# Share of the moves of a random N=24 game whose peg has a peg of its colour a knight's move away (counted on
+# the oracle's games: 0.698); only those fetch a window.
+WINDOW_SHARE = 0.70
 
 
 def journal_period(n):
@@ -75,10 +78,11 @@ def window_geometry(n):
     return {"W": w, "RP": rp, "LFB": lfb, "NW": nw, "NPC": npc}
 
 
-def design_bytes_split(n, multi_cell_fills=0.028, region_update=REGION_UPDATE_BYTES):
+def design_bytes_split(n, multi_cell_fills=0.028, region_update=REGION_UPDATE_BYTES, windows=WINDOW_SHARE):
     """Bytes the windowed step requests per env step by construction, big boards.
     A launch with j records to replay reads pegs (16 RP) + scalars (16) + the records (4 j) + the window
-    (16 NPC) + the whole region of the boards with a multi-cell fill, and writes the region words its move
+    (16 NPC, for the `windows` share of the moves that have a neighbour to link to: the others fetch none)
+    + the whole region of the boards with a multi-cell fill, and writes the region words its move
     changes (`region_update`: the cell's link words, flag pairs, the far ends' link words -- a mean over random
     games) plus its record (4 B); the P-th launch of a period, the compaction, writes pegs and scalars instead
     of a record.  Returns (per step averaged over a period, journal launch mean, compaction launch).  The
@@ -86,7 +90,7 @@ def design_bytes_split(n, multi_cell_fills=0.028, region_update=REGION_UPDATE_BY
     average and a region update dirties 32-byte sectors, so the PMC traffic is above this request count."""
     g, p = window_geometry(n), journal_period(n)
     rows = 16 * g["RP"] + 16
-    reads = [rows + 4 * j + 16 * g["NPC"] + multi_cell_fills * g["LFB"] for j in range(p)]
+    reads = [rows + 4 * j + windows * 16 * g["NPC"] + multi_cell_fills * g["LFB"] for j in range(p)]
     journal = [r + region_update + 4 for r in reads[:p - 1]]
     compaction = reads[p - 1] + region_update + rows
     jmean = sum(journal) / max(1, len(journal))

@@ -138,8 +138,9 @@ def test_design_byte_model():
     # writes the region words of its move (a mean) and its record; the compaction writes pegs and scalars instead
     per_step, journal, compaction = bench.design_bytes_split(24)
     upd = bench.REGION_UPDATE_BYTES
-    assert abs(journal - (160 + 4 * 3 + 160 + 0.028 * 432 + upd + 4)) < 1e-9
-    assert abs(compaction - (160 + 4 * 7 + 160 + 0.028 * 432 + upd + 160)) < 1e-9
+    win = bench.WINDOW_SHARE * 160  # (only a move with a neighbour to link to fetches its window)
+    assert abs(journal - (160 + 4 * 3 + win + 0.028 * 432 + upd + 4)) < 1e-9
+    assert abs(compaction - (160 + 4 * 7 + win + 0.028 * 432 + upd + 160)) < 1e-9
     assert abs(per_step - (7 * journal + compaction) / 8) < 1e-9 and bench.design_bytes(24) == per_step
     assert bench.window_geometry(24) == {"W": 18, "RP": 9, "LFB": 432, "NW": 6, "NPC": 10}
     assert bench.window_geometry(19)["NPC"] == 8 and bench.window_geometry(20)["LFB"] == 320

@@ -5,7 +5,7 @@ The step kernels issue their prefetches as inline-asm global loads and wait for 
 does not know the registers are in flight and is free to copy or spill them right after the asm statement
 (it did: a scratch spill of a register pair an iteration before its data arrived).  This script scans the ISA
 of one kernel linearly: registers written by an asm load (between ;;#ASMSTART / ;;#ASMEND) are in flight until
-the next `s_waitcnt vmcnt(0)`; any instruction OUTSIDE asm blocks that names one of them in between is reported.
+the next `s_waitcnt vmcnt(n)` retires them (all but the youngest n loads); any instruction OUTSIDE asm blocks that names one of them in between is reported.
 Linear scan = no control flow: a report is a place to look at, not a proof either way.
 
 usage: inflight_check.py file.s kernel_symbol_substring
@@ -41,11 +41,16 @@ for i in range(start, end):
         continue
     if not l or l.startswith(".") or l.endswith(":"):
         continue
-    if "s_waitcnt" in l and "vmcnt(0)" in l:
-        inflight.clear()
+    m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+    if m:
+        # one in-order counter: all but the youngest n operations are done.  Stores are not modelled, so
+        # "the youngest n asm loads stay in flight" over-states what is in flight (conservative).
+        n = int(m.group(1))
+        keep = sorted(set(inflight.values()))[-n:] if n else []
+        inflight = {r: at for r, at in inflight.items() if at in keep}
         continue
     if in_asm:
-        if l.startswith("global_load"):
+        if l.startswith("global_load") or (l.startswith("global_atomic") and " sc0" in l):  # (returning atomic)
             dst = l.split()[1].rstrip(",")
             for r in regs(dst):
                 inflight[r] = i + 1
