@@ -39,9 +39,10 @@ TRAFFIC_FILE = os.path.join("profiles", "traffic_step_kernel_n24.json")
 # about one link per move -- 16 B when the new peg is a link's west end, 4 B at the other peg otherwise --
 # and 8 B of flags for one move in eight): a model constant, the PMC write count is the measurement.
 REGION_UPDATE_BYTES = 10.0
-# Share of the moves of a random N=24 game whose peg has a peg of its colour a knight's move away (counted on
-# the oracle's games: 0.698); only those fetch a window.
-WINDOW_SHARE = 0.70
+# Window bytes a move requests, as a share of the full window of 16 NPC bytes (mean over the oracle's random N=24
+# games): 0.698 of the moves have a peg of their colour a knight's move away -- the others fetch nothing -- and
+# those request the words of the columns their candidates reach, 102 B on average: 71.4 B per move of 160.
+WINDOW_SHARE = 0.446
 
 
 def journal_period(n):
@@ -81,7 +82,7 @@ def window_geometry(n):
 def design_bytes_split(n, multi_cell_fills=0.028, region_update=REGION_UPDATE_BYTES, windows=WINDOW_SHARE):
     """Bytes the windowed step requests per env step by construction, big boards.
     A launch with j records to replay reads pegs (16 RP) + scalars (16) + the records (4 j) + the window
-    (16 NPC, for the `windows` share of the moves that have a neighbour to link to: the others fetch none)
+    (`windows` x 16 NPC: only a move with a neighbour to link to fetches, and only the columns it can touch)
     + the whole region of the boards with a multi-cell fill, and writes the region words its move
     changes (`region_update`: the cell's link words, flag pairs, the far ends' link words -- a mean over random
     games) plus its record (4 B); the P-th launch of a period, the compaction, writes pegs and scalars instead

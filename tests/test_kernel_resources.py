@@ -40,5 +40,5 @@ def test_no_scratch_and_hazard_padding(tmp_path):
     blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, flags=re.S)
     loads = [b for b in blocks if re.search(r"global_load_dword\S*\s+\S+, v\d+, s\[", b)]
     assert len(loads) > 500
-    bad = [b for b in loads if not b.lstrip().startswith("s_nop 4")]
+    bad = [b for b in loads if not re.search(r"s_nop 4\s*\n\s*global_load_dword", b)]  # (directly before the load)
     assert not bad, "asm load with a scalar base without hazard padding: %r" % bad[0]

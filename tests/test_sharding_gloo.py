@@ -138,7 +138,7 @@ def test_design_byte_model():
     # writes the region words of its move (a mean) and its record; the compaction writes pegs and scalars instead
     per_step, journal, compaction = bench.design_bytes_split(24)
     upd = bench.REGION_UPDATE_BYTES
-    win = bench.WINDOW_SHARE * 160  # (only a move with a neighbour to link to fetches its window)
+    win = bench.WINDOW_SHARE * 160  # (only a move with a neighbour to link to fetches, and only the columns it can touch)
     assert abs(journal - (160 + 4 * 3 + win + 0.028 * 432 + upd + 4)) < 1e-9
     assert abs(compaction - (160 + 4 * 7 + win + 0.028 * 432 + upd + 160)) < 1e-9
     assert abs(per_step - (7 * journal + compaction) / 8) < 1e-9 and bench.design_bytes(24) == per_step

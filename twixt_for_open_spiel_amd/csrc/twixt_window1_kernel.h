@@ -82,6 +82,8 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   constexpr int BPW = 64;
   constexpr int NS = twx::kJournalSlots - 1;  // records a journal launch may have to replay
   constexpr uint32_t kColMask = (1u << N) - 1u;
+  constexpr auto dir_mask = [](int dx) { uint32_t m = 0; for (int d = 0; d < 8; d++) if (twx::kDX[d] == dx) m |= 1u << d; return m; };
+  constexpr uint32_t kDirEast1 = dir_mask(1), kDirEast2 = dir_mask(2), kDirWest1 = dir_mask(-1), kDirWest2 = dir_mask(-2);
   static_assert(twx::kJournalChunks == 2 && W <= 32 && LFP <= 32 && WSTR == NPC + 1 && (NPC & 1) == 0, "layout");
   static_assert(RSC * 512 - 2048 <= 4095 && RJ * 512 + 7 * 128 - 2048 <= 4095, "row offsets fit the load immediates");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -137,7 +139,9 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       if (S < jpos) gload4iv<RJ * 512 + S * 128 - 2048>(jrv[S], voff_j, tile);
     });
   };
-  u32x4 wv[NPC];  // the window under way
+  u32x4 wv[NPC];  // the window under way (a lane's loads leave the pieces it does not need as they are)
+#pragma unroll
+  for (int p = 0; p < NPC; p++) wv[p] = u32x4{0u, 0u, 0u, 0u};
   auto window_piece0 = [&](int x) -> int {  // first piece of the window of a move in board column x
     const int c_lo = x - 3 < 0 ? 0 : x - 3;
     int w0 = (c_lo * N) >> 5;
@@ -161,6 +165,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   long c_idx = 0;
   int c_a = -1, c_pa = 0;
   uint32_t c_counter = 0, c_move_one = 0, c_result = 0, c_swapped = 0, c_cand = 0, c_episode = 0;
+  uint32_t c_wrange = 0;  // the bytes of its region the batch's lane fetched: offset | (length - 24) << 16
   uint32_t c_jr[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) c_jr[s] = 0u;
@@ -222,7 +227,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
 
     // ---- 2. choose the moves of batch idx ----
     int n_a = -1, n_pa = 0;
-    uint32_t n_counter = 0, n_move_one = 0, n_result = 0, n_swapped = 0, n_cand = 0, n_bits = 0, n_episode = 0;
+    uint32_t n_counter = 0, n_move_one = 0, n_result = 0, n_swapped = 0, n_cand = 0, n_bits = 0, n_episode = 0, n_wrange = 0;
     if (have) {
       const char *const tile_cur = tile_of(idx);
       __builtin_amdgcn_sched_barrier(0);
@@ -371,18 +376,34 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
         for (int r = 0; r < RP; r++)
           tile_store<true>(reinterpret_cast<uint4 *>(tw + r * 512), *reinterpret_cast<const uint4 *>(pegme + r * 256));
       }
-      // ---- the window: ten pieces of this board's region, fetched by the lane itself -- when the move can make a
-      //      link at all.  A peg without a neighbour of its colour a knight's move away (3 moves in 10 of a random
-      //      game) links nothing, gains no flag and changes no region word (tb.cc:517: the scan finds nothing):
-      //      its lane fetches nothing and the apply phase ignores what its window holds ----
-      const uint32_t voff_w = my_tile + (uint32_t)(WG::L_ROWS + q * LFB + 16 * window_piece0(x));
-      __builtin_amdgcn_sched_barrier(0);
-      if (act && cand != 0u) {
-        static_for<0, NPC>([&](auto pt) {
-          constexpr int P = decltype(pt)::value;
-          gload16iv<P * 16>(wv[P], voff_w, tile_cur);
-        });
+      // ---- the window: the pieces of this board's region that the move can touch, fetched by the lane itself.
+      //      A peg without a neighbour of its colour a knight's move away (3 moves in 10 of a random game) links
+      //      nothing, gains no flag and changes no region word (tb.cc:517: the scan finds nothing): its lane
+      //      fetches nothing and the apply phase ignores what its window holds.  Otherwise the candidates say which
+      //      columns count: a link to x+1 can only be crossed by links whose west ends lie in columns x-1, x; to
+      //      x+2: x-1..x+1; to x-1: x-2, x-1; to x-2: x-3..x-1 (twixt_geom.h kCross: the other columns' masks are
+      //      zero), the flags are those of the candidates' columns and of the peg's own.  The words of that column
+      //      range, as 16-byte pieces: 1.7 lines of 128 bytes on average instead of 2.1 for all six columns ----
+      const int piece0 = window_piece0(x);
+      const uint32_t voff_w = my_tile + (uint32_t)(WG::L_ROWS + q * LFB + 16 * piece0);
+      uint32_t wmask = 0u;
+      {
+        const int lo = (cand & kDirWest2) ? -3 : (cand & kDirWest1) ? -2 : -1;
+        const int hi = (cand & kDirEast2) ? 2 : (cand & kDirEast1) ? 1 : 0;
+        int c0 = x + lo, c1 = x + hi + 1;
+        c0 = c0 < 0 ? 0 : c0;
+        c1 = c1 > N ? N : c1;
+        const int w_lo = (c0 * N) >> 5, w_hi = (c1 * N - 1) >> 5;            // words of the column range
+        const int p_lo = (3 * w_lo) >> 1, p_hi = (3 * w_hi + 2) >> 1;        // ... their 16-byte pieces (24 B a word)
+        const int rl = p_lo - piece0, np = p_hi - p_lo;                      // first piece in the window, pieces - 1
+        if (act && cand != 0u) wmask = ((2u << np) - 1u) << rl;
+        n_wrange = (uint32_t)(16 * p_lo) | ((uint32_t)(16 * np - 8) << 16);  // byte offset; bytes - 24: see win_has
       }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NPC>([&](auto pt) {
+        constexpr int P = decltype(pt)::value;
+        gload16iv_if<P * 16>(wv[P], voff_w, tile_cur, wmask & (1u << P));
+      });
       __builtin_amdgcn_sched_barrier(0);
       n_a = a; n_pa = pa;
       n_counter = counter; n_move_one = move_one; n_result = result; n_swapped = swapped; n_cand = cand; n_episode = episode;
@@ -401,7 +422,8 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       const int x = pa / N, y = pa - x * N;
       const int player = (int)(c_counter & 1u);
       const int piece0 = window_piece0(x);
-      auto win_has = [&](int w) -> bool { return (uint32_t)(24 * w - 16 * piece0) <= (uint32_t)(16 * NPC - 24); };
+      // is word w of the region among the pieces this lane fetched?
+      auto win_has = [&](int w) -> bool { return (uint32_t)(24 * w) - (c_wrange & 0xffffu) <= (c_wrange >> 16); };
       STAMP(5);  // (no replay here: the regions in HBM are always current)
       uint32_t pend = 0, fill1 = 0;
       uint32_t counter2 = c_counter, move_one2 = c_move_one, result2 = c_result, swapped2 = c_swapped;
@@ -717,7 +739,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
     c_valid = have;
     c_idx = uniform_long(idx);
     c_a = n_a; c_pa = n_pa; c_counter = n_counter; c_move_one = n_move_one; c_result = n_result; c_swapped = n_swapped;
-    c_cand = n_cand; c_bits = n_bits; c_episode = n_episode;
+    c_cand = n_cand; c_bits = n_bits; c_episode = n_episode; c_wrange = n_wrange;
 #pragma unroll
     for (int s = 0; s < NS; s++) c_jr[s] = jr[s];
     if (have) {  // (kept in scalar registers: the loop and its phases branch on them)

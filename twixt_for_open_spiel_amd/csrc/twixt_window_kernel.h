@@ -76,6 +76,18 @@ template <int IMM>
 __device__ __forceinline__ void gload16iv(u32x4 &dst, uint32_t voff, const void *base) {
   asm volatile(TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
+// ... for the lanes whose `bit` is not zero only (the others keep what the register holds): exec is narrowed inside
+// the statement, so the instruction is always issued and there is no branch around it
+template <int IMM>
+__device__ __forceinline__ void gload16iv_if(u32x4 &dst, uint32_t voff, const void *base, uint32_t bit) {
+  uint64_t saved;
+  asm volatile("v_cmp_ne_u32 vcc, 0, %3\n\t"
+               "s_and_saveexec_b64 %1, vcc\n\t" TWX_SGPR_HAZARD_NOP "global_load_dwordx4 %0, %2, %4 offset:%5\n\t"
+               "s_mov_b64 exec, %1"
+               : "+v"(dst), "=&s"(saved)
+               : "v"(voff), "v"(bit), "s"(base), "n"(IMM)
+               : "memory", "vcc");
+}
 __device__ __forceinline__ void gload16p(u32x4 &dst, const void *addr) {  // (per-lane 64-bit address)
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
 }
