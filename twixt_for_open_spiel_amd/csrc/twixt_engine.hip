@@ -313,16 +313,17 @@ int run_step(twx_env *e, const int32_t *actions, int32_t *actions_out, uint8_t *
   const bool flush = (flags & kFlagFlush) != 0;
   const bool whole_step = !ids && rsteps == 1 && !flush;
   if (int rc = refuse_capture(e, s)) return rc;
-  if (!whole_step && !flush && e->journal_live) {
-    // journals belong to the whole-batch step launches: subset and roll-out launches work
-    // on materialised planes and rewrite their boards directly
+  // launches that rewrite their boards in place (no journaling): subset and roll-out launches, period 1, and
+  // the small whole-batch steps of the split layout.  They work on materialised planes.
+  const bool rewrite = !flush && (!whole_step || e->period == 1 ||
+                                  (e->d.lay != 0 && e->small_rewrite && (e->d.bpad / 64) * 4 <= (long)e->waves_win));
+  if (rewrite && e->journal_live) {
     if (int rc = run_step(e, nullptr, nullptr, nullptr, 0u, kFlagFlush, nullptr, 0, s)) return rc;
   }
   int jarg = e->jpos;
   if (flush) {
     flags |= kFlagCompact;  // replay what is there, write everything, clear the journals
-  } else if (!whole_step || e->period == 1 ||
-             (e->d.lay != 0 && e->small_rewrite && (e->d.bpad / 64) * 4 <= (long)e->waves_win)) {
+  } else if (rewrite) {
     // no journaling: planes rewritten in place.  (Split layout, small batches -- a search's leaves: with fewer
     // 64-board batches than a quarter of the resident waves a launch is one wave's latency, not bandwidth, and
     // the pipelined journal kernel's extra iterations cost more than the bytes it saves: 15.3 against 10.5 us

@@ -17,10 +17,11 @@
 //   * its 16 bytes of every peg row and of the scalars row are ITS board's, and its journal records are
 //     single dwords of the [slot][board] rows: everything is loaded straight into the lane that needs it
 //     (scalars and records never pass through LDS; the pegs do, for the data-dependent accesses);
-//   * its window is 10 x 16 B fetched by the lane itself out of its board's links + flags region (the
-//     memory side counts 128-byte lines, not requests: tools/window_probe3.hip);
-//   * LDS per wave: 64 windows x 176 B (the eleventh piece of a window is padding: records replayed
-//     outside the window land there) + 9 peg rows x 1 KiB = 20,480 B at N=24.
+//   * its window is up to 10 x 16 B fetched by the lane itself out of its board's links + flags region -- the
+//     pieces of the board columns its move's candidate links can touch, none at all for a move without a
+//     neighbour to link to (the memory side counts 128-byte lines, not requests: tools/window_probe3.hip);
+//   * LDS per wave: 64 windows x 176 B (the eleventh piece of a window is padding: the column extraction
+//     reads one word past the last column) + 9 peg rows x 1 KiB = 20,480 B at N=24.
 // The pipeline is step_window_kernel's: per iteration a wave moves the pegs of batch k+1 and the windows of
 // batch k into LDS, requests the rows of batch k+2, chooses the moves of batch k+1 and requests their
 // windows, then applies the moves of batch k.  Multi-cell flood fills (tb.cc:573-588) wait, two boards to a
@@ -80,7 +81,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   constexpr int W = WG::W, RP = WG::RP, RSC = WG::RSC, RJ = WG::RJ, LFB = WG::LFB, LFP = WG::LFP;
   constexpr int NW = WG::NW, NPC = WG::NPC, WSTR = WG::WSTR;
   constexpr int BPW = 64;
-  constexpr int NS = twx::kJournalSlots - 1;  // records a journal launch may have to replay
+  constexpr int NS = twx::kJournalSlots - 1;  // records a journal launch may have to replay (on the pegs and scalars)
   constexpr uint32_t kColMask = (1u << N) - 1u;
   constexpr auto dir_mask = [](int dx) { uint32_t m = 0; for (int d = 0; d < 8; d++) if (twx::kDX[d] == dx) m |= 1u << d; return m; };
   constexpr uint32_t kDirEast1 = dir_mask(1), kDirEast2 = dir_mask(2), kDirWest1 = dir_mask(-1), kDirWest2 = dir_mask(-2);
@@ -571,9 +572,8 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
     //      as one (a half-wave each, lane = board column).  So the boards wait in two pass slots: a slot that has
     //      its two boards requests their regions and is flooded after the NEXT wait (nobody reads these boards
     //      again in this launch, and the result of a move never depends on its fill); a lone board is flooded
-    //      when the batches run out.  Region pieces -> the flood buffers (over the peg rows, dead by now), the
-    //      boards' records of this period and the move itself replayed on them by eight lanes at once, the flood,
-    //      the flag words that changed stored as 8-byte pieces. ----
+    //      when the batches run out.  Region pieces (current in HBM, this move included) -> the flood buffers (over
+    //      the peg rows, dead by now), the flood, the flag words that changed stored as 8-byte pieces. ----
     auto region_of = [&](int s) -> uint32_t { return (uint32_t)(s >> 5) * (uint32_t)WG::TILE + (uint32_t)(WG::L_ROWS + (s & 31) * LFB); };
     auto flood_notes = [&](uint32_t &notes, auto half, int sq) {  // cell and pending flags of the board in lane sq -> half-wave `half`
       constexpr int Q = decltype(half)::value;

@@ -114,34 +114,6 @@ __device__ __forceinline__ void set_lane(uint32_t &v, int uniform_value) {
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(uniform_value), "n"(LANE));
 }
 
-// All link / flag updates of one journal record on a WHOLE board's links + flags region in LDS (fb: word i,
-// plane p at fb[6 i + p - 2]); one lane does the whole record (the flood pass: eight lanes, eight records).
-// Straight-line: every condition is a sign-extended record bit ANDed into the value, an empty record ORs zeros.
-template <int N>
-__device__ __forceinline__ void record_on_region(uint32_t *fb, uint32_t e) {
-  const uint32_t valid = (uint32_t)((int32_t)e >> 31);
-  const int cell = (int)(e & 1023u);
-  uint32_t *const g = fb + (cell >> 5) * 6;
-  const uint32_t bit = (1u << (cell & 31)) & valid;
-  // links whose west end is this peg (planes 0, 1 and 2, 3 are adjacent dword pairs), START | END gained
-  lds_or2(g + 0, bit & (uint32_t)sbit(e, 11), bit & (uint32_t)sbit(e, 12));
-  lds_or2(g + 2, bit & (uint32_t)sbit(e, 13), bit & (uint32_t)sbit(e, 14));
-  lds_or2(g + 4, bit & (uint32_t)sbit(e, 19), bit & (uint32_t)sbit(e, 20));
-#pragma unroll
-  for (int d = 4; d < 8; d++) {  // links whose west end is the other peg
-    const uint32_t on = (uint32_t)sbit(e, 11 + d) & valid;
-    const int tc = cell + (int)((uint32_t)(twx::kDX[d] * N + twx::kDY[d]) & on);
-    lds_or(fb + (tc >> 5) * 6 + (d - 4), (1u << (tc & 31)) & on);
-  }
-  {  // the single neighbour a fill flagged
-    const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
-    const uint32_t on_s = (uint32_t)sbit(e, 27) & valid, on_e = (uint32_t)sbit(e, 28) & valid;
-    const int tf = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
-    const int t = (on_s | on_e) ? tf : cell;  // (no fill: the direction bits are meaningless)
-    lds_or2(fb + (t >> 5) * 6 + 4, (1u << (t & 31)) & on_s, (1u << (t & 31)) & on_e);
-  }
-}
-
 template <int N>
 __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, long bpad, long batch,
                                                  const int32_t *__restrict__ actions, int32_t *__restrict__ actions_out,
@@ -645,13 +617,17 @@ __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, 
   }  // batch loop
 }
 
-// compactions and flushes: the whole tile in LDS (19.5 KiB at N=24), eight waves per CU
+// Whole tiles rewritten in place: the whole-batch step of batches too small to fill the chip (a search's leaves:
+// twixt_engine.hip run_step).  The whole tile in LDS (19.5 KiB at N=24), eight waves per CU.  Such launches work
+// on materialised boards (run_step flushes a live journal first; the regions in HBM are current at any time, so
+// records must never be replayed on them): the journal position is zero by construction.
 template <int N>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void step_window_full_kernel(
     char *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
-  step_window_full_body<N>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ticket, tbase, nstatic);
+  (void)jpos;
+  step_window_full_body<N>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, 0, ticket, tbase, nstatic);
 }
 
 #endif  // TWIXT_WINDOW_KERNEL_H_
