@@ -56,8 +56,8 @@ def algo_bytes(n):
 
 
 def split_layout(n):
-    """Big boards (N >= 19, TWX_SMALL_CHT): split layout, windowed step (twixt_window1_kernel.h)."""
-    return 2 * ((n * n + 31) // 32) + 3 > 25
+    """Big boards (N >= 17, TWX_SPLIT_CHT): split layout, windowed step (twixt_window1_kernel.h)."""
+    return 2 * ((n * n + 31) // 32) + 3 > 19
 
 
 def step_kernel_name(n):

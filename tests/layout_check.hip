@@ -44,7 +44,7 @@ int main() {
   // ---- split layout (the big boards, step_window_kernel): every word of every plane, every scalar and
   //      every journal record of a board has its own dword inside the board's tile; pegs / scalars /
   //      journal in [row][board] rows of 512 B, links + flags board-major behind them ----
-  for (int n = 19; n <= 24; n++) {
+  for (int n = 17; n <= 24; n++) {
     const int W = (n * n + 31) / 32, RP = split_peg_rows(W), RA = split_rows(W), LFB = split_lf_bytes(W);
     const long TD = split_tile_bytes(W) / 4, boards = 5 * 32;
     CHECK(split_tile_bytes(W) % 128 == 0 || n != 24, "n=24 tiles are whole 128-byte lines");

@@ -1,4 +1,4 @@
-"""GPU parity of the step kernels of the big boards (N >= 19) against the CPU oracle: the default path --
+"""GPU parity of the step kernels of the big boards (split layout: N >= 17; pair kernel: N >= 19) against the CPU oracle: the default path --
 split layout, step_window1_kernel (windowed journal launches, one lane per board) + step_window_full_kernel
 (compactions, flushes) -- and the two older ones on the chunk layout, step_pair_kernel (TWX_WINDOW=0: two lanes
 per board, whole boards streamed) and step_kernel64 (TWX_PAIR=0: one lane per board) -- every board, every
@@ -26,7 +26,10 @@ def torch_mod():
 KERNEL_PATHS = {"window": {}, "pair": {"TWX_WINDOW": "0"}, "lane": {"TWX_PAIR": "0"}}
 
 
-@pytest.mark.parametrize("n,batch,steps", [(19, 1000, 420), (21, 700, 150), (22, 330, 200), (24, 1500, 640)])
+# (N = 17, 18: split layout and windowed step as well -- TWX_SPLIT_CHT; their other two paths are the small-board
+# kernel on the chunk layout)
+@pytest.mark.parametrize("n,batch,steps", [(17, 900, 330), (18, 640, 380), (19, 1000, 420), (21, 700, 150), (22, 330, 200),
+                                           (24, 1500, 640)])
 @pytest.mark.parametrize("path", ["window", "pair", "lane"])
 def test_every_step_against_the_oracle(torch_mod, n, batch, steps, path, monkeypatch):
     import oracle_binding as ob
@@ -164,7 +167,7 @@ def test_ragged_batches(torch_mod, batch, pair, monkeypatch):
     boards never move and are never reported): a few boards, whole-batch steps, N=24 and N=19."""
     import oracle_binding as ob
     monkeypatch.setenv("TWX_PAIR", str(pair))
-    for n, steps in ((24, 60), (19, 40)):
+    for n, steps in ((24, 60), (19, 40), (18, 40)):
         env = make_env(n, batch, first=7)
         acts = []
         for _ in range(steps):
@@ -253,7 +256,7 @@ def test_external_actions_swaps_and_illegal_moves(torch_mod, pair, monkeypatch):
     env.close()
 
 
-@pytest.mark.parametrize("n,batch", [(22, 330), (12, 450)])
+@pytest.mark.parametrize("n,batch", [(22, 330), (17, 410), (12, 450)])
 def test_whole_batch_and_listed_boards_interleaved(torch_mod, n, batch):
     """Whole-batch steps (which journal), listed-boards steps, play-outs of a few boards and status
     queries on one handle, in an order that leaves journal rows stale and boards reset in the middle

@@ -54,6 +54,13 @@ int fail(int code, const std::string &msg) {
 #ifndef TWX_SMALL_CHT
 #define TWX_SMALL_CHT 25  // N <= 18: measured +19 % (N=17), +7 % (N=18); -3 % / -6 % at N=19 / 20
 #endif
+// board sizes whose state is MORE than this many chunks (N >= 17) keep it in the split layout and take the
+// windowed whole-batch step (measured against the chunk layout's kernels at B = 2^20: +15 % at N=17, +14 % at
+// N=18; -7..-24 % at N = 12..16, where the windowed kernel's fixed cost -- about 0.078 ms -- is above what
+// streaming the whole board takes).  Their play-outs and listed-boards steps keep the small-board kernel.
+#ifndef TWX_SPLIT_CHT
+#define TWX_SPLIT_CHT 19
+#endif
 // board sizes whose state is at most this many chunks (N <= 16) write back with plain stores
 #ifndef TWX_PLAIN_STORE_CHT
 #define TWX_PLAIN_STORE_CHT 19
@@ -77,6 +84,12 @@ hipError_t launch_step(uint4 *state, long bpad, long batch, const int32_t *actio
   hipLaunchKernelGGL((K), dim3((unsigned)grid), dim3(kWave), lds_bytes, s, state, bpad, batch, actions, \
                      actions_out, status, seed, first_id, flags, jpos, ids, nsub, rsteps, rpw, ticket, ticket_base, nstatic)
   if constexpr (twx::Geo<N>::CHT <= TWX_SMALL_CHT) {
+    if constexpr (twx::Geo<N>::CHT > TWX_SPLIT_CHT) {
+      if (split) {
+        if (ids) TWX_LAUNCH((step_kernel64_small<N, true, true>)); else TWX_LAUNCH((step_kernel64_small<N, false, true>));
+        return hipGetLastError();
+      }
+    }
     if (ids) TWX_LAUNCH((step_kernel64_small<N, true>)); else TWX_LAUNCH((step_kernel64_small<N, false>));
   } else if (split) {  // the handle's state is in the split layout (listed boards, play-outs)
     if (ids) TWX_LAUNCH((step_kernel64<N, true, true>)); else TWX_LAUNCH((step_kernel64<N, false, true>));
@@ -135,7 +148,7 @@ template <int N>
 hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *actions, int32_t *actions_out,
                          uint8_t *status, uint32_t seed, uint32_t first_id, int flags, int jpos, int waves,
                          uint32_t *ticket, TicketBases ticket_base, int nstatic, hipStream_t s) {
-  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+  if constexpr (twx::Geo<N>::CHT > TWX_SPLIT_CHT) {
     const long nbatch = bpad / 32;
     const long grid = nbatch < (long)waves ? nbatch : (long)waves;
     const bool full = (flags & kFlagWholeTile) != 0;
@@ -157,7 +170,7 @@ hipError_t launch_window(uint4 *state, long bpad, long batch, const int32_t *act
 // resident waves per CU of the journal (0) / the rewriting (1) instantiation
 template <int N>
 int window_occupancy_1() {
-  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+  if constexpr (twx::Geo<N>::CHT > TWX_SPLIT_CHT) {
     int blocks = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window1_kernel<N>, kWave, (size_t)Win1Geo<N>::lds_bytes) != hipSuccess)
       return 0;
@@ -167,7 +180,7 @@ int window_occupancy_1() {
 }
 template <int N>
 int window_occupancy_f() {
-  if constexpr (twx::Geo<N>::CHT > TWX_SMALL_CHT) {
+  if constexpr (twx::Geo<N>::CHT > TWX_SPLIT_CHT) {
     int blocks = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, step_window_full_kernel<N>, kWave, (size_t)WinGeo<N>::lds_bytes_full) != hipSuccess)
       return 0;
@@ -486,7 +499,7 @@ int twx_create(int n, int64_t batch, int device, uint64_t first_board_id, twx_en
   // the big boards (whole-batch step = two lanes per board) live in the split layout and step through
   // step_window_kernel; TWX_WINDOW=0 keeps them in the chunk layout on step_pair_kernel, TWX_PAIR=0 on the
   // one-lane kernel (both for A/B runs and for the options only that kernel has: rolling compaction)
-  e->d.lay = (e->d.CHT > TWX_SMALL_CHT && env_int("TWX_WINDOW", 1, 0, 1) != 0 && env_int("TWX_PAIR", 1, 0, 1) != 0 &&
+  e->d.lay = (e->d.CHT > TWX_SPLIT_CHT && env_int("TWX_WINDOW", 1, 0, 1) != 0 && env_int("TWX_PAIR", 1, 0, 1) != 0 &&
               env_int("TWX_ROLLING", 0, 0, 1) == 0 && step_tables().wocc_1[n]() > 0 && step_tables().wocc_f[n]() > 0)
                  ? 1 : 0;
   e->jpos = 0;

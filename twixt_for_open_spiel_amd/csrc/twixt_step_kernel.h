@@ -741,14 +741,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1))) v
 // by themselves -- and a register more or less was worth 6 % (N=6: 0.0432 ms per 2^20-board step with
 // four waves, 0.0461 with three).
 constexpr int small_min_waves(int n) { return (n * n + 31) / 32 <= 2 && TWX_SMALL_MIN_WAVES < 4 ? 4 : TWX_SMALL_MIN_WAVES; }
-template <int N, bool SUB>
+template <int N, bool SUB, bool SPLIT = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(small_min_waves(N), 8))) void step_kernel64_small(
     uint4 *__restrict__ state, long bpad, long batch, const int32_t *__restrict__ actions,
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, const int32_t *__restrict__ ids, long nsub, int rsteps, int rpw, uint32_t *__restrict__ ticket,
     TicketBases tbase, int nstatic) {
-  step_body<N, SUB>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
-                    rsteps, rpw, ticket, tbase, nstatic);
+  step_body<N, SUB, SPLIT>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, jpos, ids, nsub,
+                           rsteps, rpw, ticket, tbase, nstatic);
 }
 
 #endif  // TWIXT_STEP_KERNEL_H_

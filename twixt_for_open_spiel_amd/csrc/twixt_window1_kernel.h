@@ -85,7 +85,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   constexpr uint32_t kColMask = (1u << N) - 1u;
   constexpr auto dir_mask = [](int dx) { uint32_t m = 0; for (int d = 0; d < 8; d++) if (twx::kDX[d] == dx) m |= 1u << d; return m; };
   constexpr uint32_t kDirEast1 = dir_mask(1), kDirEast2 = dir_mask(2), kDirWest1 = dir_mask(-1), kDirWest2 = dir_mask(-2);
-  static_assert(twx::kJournalChunks == 2 && W <= 32 && LFP <= 32 && WSTR == NPC + 1 && (NPC & 1) == 0, "layout");
+  static_assert(twx::kJournalChunks == 2 && W <= 32 && LFP <= 32 && WSTR >= NPC && (WSTR & 1) == 1, "layout");
   static_assert(RSC * 512 - 2048 <= 4095 && RJ * 512 + 7 * 128 - 2048 <= 4095, "row offsets fit the load immediates");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
