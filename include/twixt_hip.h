@@ -31,10 +31,10 @@
  *     every other entry point first materialises the journal and is unaffected.
  *   - tuning knobs read once by twx_create from the environment: TWX_JOURNAL_PERIOD
  *     (1..8; default by board size: 1 for N <= 9, 2 for N = 10..12, 4 for N = 13..17, 8 above;
- *     1 = rewrite the planes every step), TWX_WINDOW (0/1, default 1: boards of N >= 19 live in
- *     the split layout and step through the windowed kernels; 0: chunk layout, step_pair_kernel),
+ *     1 = rewrite the planes every step), TWX_WINDOW (0/1, default 1: boards of N >= 17 live in
+ *     the split layout and step through the windowed kernels; 0: chunk layout, round 2's kernels),
  *     TWX_PAIR (0/1, default 1; 0: chunk layout, one lane per board), TWX_SMALL_BATCH_REWRITE (0/1,
- *     default 1: batches of N >= 19 too small to fill the chip rewrite their boards every step
+ *     default 1: batches of N >= 17 too small to fill the chip rewrite their boards every step
  *     instead of journalling -- one wave's latency decides there), TWX_PINGPONG (0/1, default 1:
  *     alternate the batch order between launches), TWX_WAVES_PER_CU (default: occupancy),
  *     TWX_DYNAMIC (0/1, default 1: the last rounds of a launch are handed out by ticket
