@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
-    # Big boards (N >= 19): batches too small to fill the chip normally skip the journal (they rewrite their
+    # Big boards (split layout, N >= 17): batches too small to fill the chip normally skip the journal (they rewrite their
     # boards every step: twixt_engine.hip run_step).  The parity tests are small batches and are there to test
     # the journal path -- the windowed kernel the benchmark runs -- so they switch that routing off;
     # tests/test_gpu_pair_kernel.py::test_small_batches_rewrite_in_place covers the default.

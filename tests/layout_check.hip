@@ -75,6 +75,40 @@ int main() {
     for (size_t i = 0; i < owner.size(); i++) { CHECK(owner[i] <= 1, "n=%d: dword %zu claimed %d times", n, i, owner[i]); claimed += owner[i]; }
     CHECK(claimed == boards * (8 * W + 4 + twx::kJournalSlots), "n=%d: %ld dwords claimed", n, claimed);
   }
+  // ---- the window of a move (step_window1_kernel): for every size of the split layout, every board column and
+  //      every set of candidate directions, the pieces win_range() names lie inside the window's NPC pieces
+  //      and cover every word that holds a bit the move can touch: the link columns of the candidates'
+  //      crossing masks (twixt_geom.h kCross, independent of win_range's own column rule), the flag columns
+  //      of the candidates and the peg's own column ----
+  for (int n = 17; n <= 24; n++) {
+    const int W = (n * n + 31) / 32, LFP = split_lf_bytes(W) / 16, NPC = win_pieces(n, W);
+    for (int x = 0; x < n; x++) {
+      const int p0 = win_piece0(n, W, x);
+      CHECK(p0 >= 0 && p0 + NPC <= LFP, "n=%d x=%d: window outside the region", n, x);
+      for (uint32_t cand = 1; cand < 256; cand++) {
+        const WinRange r = win_range(n, cand, x);
+        CHECK(r.np >= 1 && r.p_lo >= p0 && r.p_lo + r.np <= p0 + NPC - 1, "n=%d x=%d cand=%02x: pieces %d..%d outside window %d..%d",
+              n, x, cand, r.p_lo, r.p_lo + r.np, p0, p0 + NPC - 1);
+        bool need[32] = {};
+        need[x] = true;  // own flags, own link words
+        for (int d = 0; d < 8; d++) {
+          if (!((cand >> d) & 1u)) continue;
+          const int cf = x + twx::kDX[d];
+          if (cf >= 0 && cf < n) need[cf] = true;  // the candidate's flags (and its link word for a west link)
+          for (int i = 0; i < twx::kWinCols; i++) {
+            const int c = x - 3 + i;
+            if (twx::kCross.m[d][i] != 0u && c >= 0 && c < n) need[c] = true;
+          }
+        }
+        for (int c = 0; c < n; c++) {
+          if (!need[c]) continue;
+          for (int w = (c * n) >> 5; w <= ((c + 1) * n - 1) >> 5; w++)
+            CHECK(24 * w >= 16 * r.p_lo && 24 * w + 24 <= 16 * (r.p_lo + r.np + 1), "n=%d x=%d cand=%02x: word %d of column %d not fetched",
+                  n, x, cand, w, c);
+        }
+      }
+    }
+  }
   // ---- backward batch order: a bijection that reverses blocks of 8 and keeps i % 8 ----
   for (long nb : {1L, 7L, 8L, 9L, 16L, 37L, 64L, 1000L, 16384L, 32768L, 32771L}) {
     std::set<long> seen;

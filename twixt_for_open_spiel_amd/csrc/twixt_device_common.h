@@ -150,6 +150,47 @@ __host__ __device__ __forceinline__ long split_journal_index(int s, long b, int 
   return (b >> 5) * (split_tile_bytes(W) >> 2) + (long)(split_peg_rows(W) + 1) * 128 + (long)s * 32 + (b & 31);
 }
 
+// ---- the window of a move in board column x (twixt_window1_kernel.h): which 16-byte pieces of the board's region.
+//      Host-checkable arithmetic (tests/layout_check.hip proves the coverage for every size, column and
+//      candidate set from the crossing masks of twixt_geom.h). ----
+constexpr int win_words(int n, int W) {  // columns x-3 .. x+2 = 6n bits from a bit offset < 32
+  const int nw = (6 * n + 31 + 31) / 32;
+  return nw < W ? nw : W;
+}
+constexpr int win_pieces(int n, int W) {  // (24 w0 is 8 bytes off a piece for odd w0)
+  const int npc = (24 * win_words(n, W) + 8 + 15) / 16, lfp = split_lf_bytes(W) / 16;
+  return npc < lfp ? npc : lfp;
+}
+__host__ __device__ constexpr int win_piece0(int n, int W, int x) {  // first piece of the full window
+  const int c_lo = x - 3 < 0 ? 0 : x - 3;
+  int w0 = (c_lo * n) >> 5;
+  w0 = w0 > W - win_words(n, W) ? W - win_words(n, W) : w0;
+  const int piece0 = (24 * w0) >> 4, last = split_lf_bytes(W) / 16 - win_pieces(n, W);
+  return piece0 > last ? last : piece0;
+}
+constexpr uint32_t win_dir_mask(int dx) {  // the directions (twx::kDX) that reach column x + dx
+  uint32_t m = 0;
+  for (int d = 0; d < 8; d++)
+    if (twx::kDX[d] == dx) m |= 1u << d;
+  return m;
+}
+struct WinRange {
+  int p_lo, np;  // first piece (of the region), pieces - 1
+};
+// The pieces a move with candidate links `cand` (one bit per direction, not zero) can touch: a link to column x+1
+// is crossed only by links whose west ends lie in columns x-1, x; to x+2: x-1..x+1; to x-1: x-2, x-1; to x-2:
+// x-3..x-1 (twixt_geom.h kCross); the flags of the candidates' columns and of the peg's own.
+__host__ __device__ constexpr WinRange win_range(int n, uint32_t cand, int x) {
+  const int lo = (cand & win_dir_mask(-2)) ? -3 : (cand & win_dir_mask(-1)) ? -2 : -1;
+  const int hi = (cand & win_dir_mask(2)) ? 2 : (cand & win_dir_mask(1)) ? 1 : 0;
+  int c0 = x + lo, c1 = x + hi + 1;
+  c0 = c0 < 0 ? 0 : c0;
+  c1 = c1 > n ? n : c1;
+  const int w_lo = (c0 * n) >> 5, w_hi = (c1 * n - 1) >> 5;      // words of the column range
+  const int p_lo = (3 * w_lo) >> 1, p_hi = (3 * w_hi + 2) >> 1;  // ... their 16-byte pieces (24 B a word)
+  return WinRange{p_lo, p_hi - p_lo};
+}
+
 template <bool NT>
 __device__ __forceinline__ void tile_store_word(uint32_t *p, uint32_t v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);

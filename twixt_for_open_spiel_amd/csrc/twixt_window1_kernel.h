@@ -83,8 +83,6 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   constexpr int BPW = 64;
   constexpr int NS = twx::kJournalSlots - 1;  // records a journal launch may have to replay (on the pegs and scalars)
   constexpr uint32_t kColMask = (1u << N) - 1u;
-  constexpr auto dir_mask = [](int dx) { uint32_t m = 0; for (int d = 0; d < 8; d++) if (twx::kDX[d] == dx) m |= 1u << d; return m; };
-  constexpr uint32_t kDirEast1 = dir_mask(1), kDirEast2 = dir_mask(2), kDirWest1 = dir_mask(-1), kDirWest2 = dir_mask(-2);
   static_assert(twx::kJournalChunks == 2 && W <= 32 && LFP <= 32 && WSTR >= NPC && (WSTR & 1) == 1, "layout");
   static_assert(RSC * 512 - 2048 <= 4095 && RJ * 512 + 7 * 128 - 2048 <= 4095, "row offsets fit the load immediates");
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -143,13 +141,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   u32x4 wv[NPC];  // the window under way (a lane's loads leave the pieces it does not need as they are)
 #pragma unroll
   for (int p = 0; p < NPC; p++) wv[p] = u32x4{0u, 0u, 0u, 0u};
-  auto window_piece0 = [&](int x) -> int {  // first piece of the window of a move in board column x
-    const int c_lo = x - 3 < 0 ? 0 : x - 3;
-    int w0 = (c_lo * N) >> 5;
-    w0 = w0 > W - NW ? W - NW : w0;
-    const int piece0 = (24 * w0) >> 4;
-    return piece0 > LFP - NPC ? LFP - NPC : piece0;
-  };
+  auto window_piece0 = [&](int x) -> int { return win_piece0(N, W, x); };  // first piece of the window of a move in column x
 
   long idx = blockIdx.x;  // the launcher guarantees gridDim.x <= nbatch
   long round = 0;
@@ -389,16 +381,9 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
       const uint32_t voff_w = my_tile + (uint32_t)(WG::L_ROWS + q * LFB + 16 * piece0);
       uint32_t wmask = 0u;
       {
-        const int lo = (cand & kDirWest2) ? -3 : (cand & kDirWest1) ? -2 : -1;
-        const int hi = (cand & kDirEast2) ? 2 : (cand & kDirEast1) ? 1 : 0;
-        int c0 = x + lo, c1 = x + hi + 1;
-        c0 = c0 < 0 ? 0 : c0;
-        c1 = c1 > N ? N : c1;
-        const int w_lo = (c0 * N) >> 5, w_hi = (c1 * N - 1) >> 5;            // words of the column range
-        const int p_lo = (3 * w_lo) >> 1, p_hi = (3 * w_hi + 2) >> 1;        // ... their 16-byte pieces (24 B a word)
-        const int rl = p_lo - piece0, np = p_hi - p_lo;                      // first piece in the window, pieces - 1
-        if (act && cand != 0u) wmask = ((2u << np) - 1u) << rl;
-        n_wrange = (uint32_t)(16 * p_lo) | ((uint32_t)(16 * np - 8) << 16);  // byte offset; bytes - 24: see win_has
+        const WinRange wr = win_range(N, cand, x);  // (twixt_device_common.h; coverage proved in tests/layout_check.hip)
+        if (act && cand != 0u) wmask = ((2u << wr.np) - 1u) << (wr.p_lo - piece0);
+        n_wrange = (uint32_t)(16 * wr.p_lo) | ((uint32_t)(16 * wr.np - 8) << 16);  // byte offset; bytes - 24: see win_has
       }
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, NPC>([&](auto pt) {

@@ -39,11 +39,9 @@ struct WinGeo {
   static constexpr int LFP = LFB / 16;             // ... in 16-byte pieces
   static constexpr long TILE = split_tile_bytes(W);
   // window: board columns x-3 .. x+2 = 6N bits from a bit offset < 32: NW words of every plane
-  static constexpr int NW0 = (6 * N + 31 + 31) / 32;
-  static constexpr int NW = NW0 < W ? NW0 : W;
-  // ... fetched as NPC 16-byte pieces from piece (24 w0) >> 4 on (24 w0 is 8 bytes off a piece for odd w0)
-  static constexpr int NPC0 = (24 * NW + 8 + 15) / 16;
-  static constexpr int NPC = NPC0 < LFP ? NPC0 : LFP;
+  static constexpr int NW = win_words(N, W);
+  // ... fetched as NPC 16-byte pieces from piece (24 w0) >> 4 on (twixt_device_common.h win_piece0 / win_range)
+  static constexpr int NPC = win_pieces(N, W);
   static constexpr int WSTR = NPC | 1;             // LDS stride of a board's window, pieces (odd: banks; the extra piece is padding)
   // LDS of step_window_full_kernel (bytes): the rows, then the 32 whole regions as in the tile
   static constexpr int L_ROWS = RA * 512;
