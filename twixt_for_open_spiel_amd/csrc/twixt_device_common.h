@@ -119,7 +119,7 @@ __host__ __device__ __forceinline__ long journal_word_index(int s, long b, int t
   return ((((b >> ts) * cht + (cht - twx::kJournalChunks)) << ts) << 2) + ((long)s << ts) + (b & ((1L << ts) - 1));
 }
 // ---------------------------------------------------------------------------
-// SPLIT layout (round 3; the big boards, N >= 19, whose whole-batch step is step_window_kernel,
+// SPLIT layout (round 3; the big boards, N >= 17 -- TWX_SPLIT_CHT --, whose whole-batch step is step_window1_kernel,
 // twixt_window_kernel.h).  A step needs ALL of a board's pegs (legal mask, k-th legal action) but its
 // links and border flags only in the six board columns around the move, so the two live apart:
 //   tile of 32 boards = RA rows of 512 B, [row][board] x 16 B, streamed by every launch:

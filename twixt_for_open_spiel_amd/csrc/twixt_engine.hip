@@ -5,11 +5,15 @@
 // SetPegAndLinks / ExploreLocalGraph / UpdateResult, twixt.h:86-104
 // LegalActions / DoApplyAction): one fused kernel launch = one env step on
 // every board of a handle.
-//   * step_pair_kernel<N> (twixt_pair_kernel.h, N >= 19): 32 boards per wave,
-//     two lanes per board, 8 waves per CU;
-//   * step_kernel64[_small]<N,SUB> (twixt_step_kernel.h): 64 boards per wave,
-//     one lane per board: N <= 18, listed-boards and fused play-out launches.
-//   Both: a persistent wave streams its boards (CHT 16-byte chunks each, tiles
+//   * step_window1_kernel<N> (twixt_window1_kernel.h, N >= 17, split layout): 64 boards per
+//     wave, one lane per board; a persistent, software-pipelined wave streams its boards' pegs
+//     and fetches of their links and flags only what the chosen move can touch;
+//     step_window_full_kernel<N> (twixt_window_kernel.h): whole tiles, for small batches;
+//   * step_kernel64[_small]<N,SUB[,SPLIT]> (twixt_step_kernel.h): 64 boards per wave,
+//     one lane per board: N <= 16, listed-boards and fused play-out launches;
+//   * step_pair_kernel<N> (twixt_pair_kernel.h, N >= 19, chunk layout, TWX_WINDOW=0): 32
+//     boards per wave, two lanes per board -- round 2's kernel, kept for A/B runs.
+//   The chunk-layout kernels: a persistent wave streams its boards (CHT 16-byte chunks each, tiles
 //   of the state array, twixt_device_common.h) into LDS with coalesced 1 KiB
 //   loads prefetched a batch ahead, works on them there, and writes back one
 //   32-bit journal record per board -- the state is log-structured;

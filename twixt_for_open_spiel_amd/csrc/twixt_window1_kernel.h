@@ -1,4 +1,4 @@
-// twixt_window1_kernel.h -- step_window1_kernel<N>: the whole-batch step of the big boards (N >= 19) on the SPLIT
+// twixt_window1_kernel.h -- step_window1_kernel<N>: the whole-batch step of the big boards (N >= 17) on the SPLIT
 // layout (journal launches, compactions and flushes), ONE LANE PER BOARD, 64 boards per wave, software-pipelined.
 // Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
 #ifndef TWIXT_WINDOW1_KERNEL_H_

@@ -1,6 +1,6 @@
-// twixt_window_kernel.h -- the big boards (N >= 19) on the SPLIT layout (twixt_device_common.h): geometry of the
+// twixt_window_kernel.h -- the big boards (N >= 17) on the SPLIT layout (twixt_device_common.h): geometry of the
 // window of a move (WinGeo), the inline-asm load / LDS-write helpers of the windowed kernels, and
-// step_window_full_kernel<N>: the launches that rewrite everything (compactions, flushes, small batches).
+// step_window_full_kernel<N>: whole tiles rewritten in place (the steps of batches too small to fill the chip).
 // Part of libtwixt_hip.so; included by twixt_engine.hip only (device code, anonymous namespace).
 #ifndef TWIXT_WINDOW_KERNEL_H_
 #define TWIXT_WINDOW_KERNEL_H_
