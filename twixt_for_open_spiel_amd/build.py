@@ -19,8 +19,11 @@ def hipcc():
 
 # keep the ticket draw of the dynamic batch order a plain asynchronous atomic: the atomic
 # optimizer would turn it into a wave reduction that waits for the result at once
+# -cuid: a fixed compile-unit id.  By default hipcc hashes the source file's absolute path into the names of the
+# anonymous-namespace kernels, so the same sources built in another directory gave another binary -- and
+# bench.py believes a committed PMC traffic measurement only for the binary it was taken on (lib_stamp()).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-cuid=twixt_hip"]
 
 
 def source_stamp():
