@@ -79,7 +79,7 @@ __device__ __forceinline__ void step_window1_body(char *__restrict__ state, long
   using WG = WinGeo<N>;
   using W1 = Win1Geo<N>;
   constexpr int W = WG::W, RP = WG::RP, RSC = WG::RSC, RJ = WG::RJ, LFB = WG::LFB, LFP = WG::LFP;
-  constexpr int NW = WG::NW, NPC = WG::NPC, WSTR = WG::WSTR;
+  constexpr int NPC = WG::NPC, WSTR = WG::WSTR;
   constexpr int BPW = 64;
   constexpr int NS = twx::kJournalSlots - 1;  // records a journal launch may have to replay (on the pegs and scalars)
   constexpr uint32_t kColMask = (1u << N) - 1u;

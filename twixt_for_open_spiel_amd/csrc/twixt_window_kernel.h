@@ -116,12 +116,12 @@ template <int N>
 __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, long bpad, long batch,
                                                  const int32_t *__restrict__ actions, int32_t *__restrict__ actions_out,
                                                  uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
-                                                 int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
+                                                 uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
   using G = twx::Geo<N>;
   using WG = WinGeo<N>;
-  constexpr int W = WG::W, RP = WG::RP, RSC = WG::RSC, RJ = WG::RJ, RA = WG::RA, LFB = WG::LFB, LFP = WG::LFP;
+  constexpr int W = WG::W, RP = WG::RP, RSC = WG::RSC, LFB = WG::LFB, LFP = WG::LFP;
   constexpr int BPW = 32;               // boards per wave
-  constexpr int NJA = (RA + 1) / 2;     // row pairs: lane half h moves rows 2j + h
+  constexpr int NJA = (RSC + 2) / 2;    // row pairs: lane half h moves rows 2j + h of the pegs and scalars (rows 0..RSC)
   constexpr int RPH = (RP + 1) / 2;     // peg rows the lower lane scans (the upper one: the rest)
   constexpr int NLF = (32 * LFP + 63) / 64;  // instructions that move the tile's links + flags regions
   constexpr uint32_t kColMask = (1u << N) - 1u;
@@ -159,26 +159,25 @@ __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, 
   constexpr int D_REG = WG::L_ROWS / 4;                      // the 32 whole regions, as in the tile
   uint32_t *const rowme = lds + (bl << 2);                   // this board's 16 bytes of row r: rowme + 128 r
   uint32_t *const sc = rowme + RSC * 128;                    // scalars
-  uint32_t *const jrow = lds + RJ * 128 + bl;                // journal record s of this board: jrow[32 s]
   // peg word i of player p: rowme[(i >> 1) * 128 + (i & 1) * 2 + p]
   auto pegw = [&](int i) -> uint32_t * { return rowme + (i >> 1) * 128 + (i & 1) * 2; };
 
-  // ---- prefetch of a batch's rows: lane half h moves rows 2j + h (the journal rows whole: a flush reads
-  //      every slot up to jpos, and nobody minds the rest) ----
+  // ---- prefetch of a batch's rows: lane half h moves rows 2j + h (pegs and scalars; the journal rows are
+  //      neither read nor written: these launches work on materialised boards) ----
   u32x4 rowv[NJA];
   uint32_t voff_rows = (uint32_t)bl * 16u + (uint32_t)h * 512u + 4096u;
   asm volatile("" : "+v"(voff_rows));
   auto load_rows = [&](const char *tile) {
     static_for<0, NJA>([&](auto jt) {
       constexpr int J = decltype(jt)::value;
-      if (2 * J + h < RA) gload16i<J * 1024 - 4096>(rowv[J], voff_rows, tile);
+      if (2 * J + h <= RSC) gload16i<J * 1024 - 4096>(rowv[J], voff_rows, tile);
     });
   };
   const uint32_t lds_rows = lds0 + (uint32_t)h * 512u + (uint32_t)bl * 16u;
   auto fill_rows = [&]() {
     static_for<0, NJA>([&](auto jt) {
       constexpr int J = decltype(jt)::value;
-      if (2 * J + h < RA) lwrite16i<J * 1024>(lds_rows, rowv[J]);
+      if (2 * J + h <= RSC) lwrite16i<J * 1024>(lds_rows, rowv[J]);
     });
   };
   // ---- the tile's 32 links + flags regions, contiguous in HBM and in LDS alike ----
@@ -212,7 +211,6 @@ __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, 
   const int wsh = up ? 16 : 0;              // their byte positions in a crossing window
   const int sgn = up ? 1 : -1;              // side of the knight neighbours this lane looks at
   const int dflip = up ? 0 : 7;             // direction numbering: lower lane d = 7 - (upper lane's d)
-  const int own_sh = 11 + 2 * h;            // record bit of link 2h
   const int dlt0 = up ? twx::kDX[6] * N + twx::kDY[6] : twx::kDX[4] * N + twx::kDY[4];
   const int dlt1 = up ? twx::kDX[7] * N + twx::kDY[7] : twx::kDX[5] * N + twx::kDY[5];
 
@@ -238,17 +236,8 @@ __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, 
     uint32_t counter = sv.x & 0xffffu, move_one = sv.x >> 16;
     uint32_t result = sv.y & 0xffu, swapped = (sv.y >> 8) & 1u;
     uint32_t episode = sv.z;
-    // the stored scalars are as old as the planes: advance them by the journal records first
-    uint32_t jbase = (sv.y >> twx::kJBaseShift) & 15u;  // first journal slot that belongs to this board's game
-    uint32_t jr[twx::kJournalSlots];
-#pragma unroll
-    for (int s = 0; s < twx::kJournalSlots; s++) {
-      const uint32_t e = (s < jpos) ? jrow[s * BPW] : 0u;  // (wave-uniform; slots from jpos on are stale or not loaded)
-      jr[s] = ((uint32_t)s >= jbase) ? e : 0u;
-    }
-#pragma unroll
-    for (int s = 0; s < twx::kJournalSlots - 1; s++)
-      if (s < jpos) twx::journal_scalars(jr[s], counter, move_one, result, swapped);
+    // (whole-tile launches work on materialised boards: the stored scalars are current, there is no record to
+    // replay, and what they write back carries journal base zero)
     const bool was_reset = random && (flags & kFlagAutoReset) && result != 0u && inb;
     if (__ballot(was_reset)) {  // rare: one board in ~520 per step
       if (was_reset) {
@@ -265,58 +254,11 @@ __device__ __forceinline__ void step_window_full_body(char *__restrict__ state, 
             *reinterpret_cast<uint2 *>(fbme + 6 * i + 4) =
                 make_uint2(G::tab.init[twx::kPlaneStart * W + i], G::tab.init[twx::kPlaneEnd * W + i]);
           }
-#pragma unroll
-        for (int s = 0; s < twx::kJournalSlots; s++) jr[s] = 0u;  // nothing to replay on the empty board
-        jbase = (uint32_t)jpos;  // the records before this launch's slot belong to the finished game
         counter = 0; move_one = 0; result = 0; swapped = 0; episode += 1;
       }
       wave_sync();
     }
-    // ---- replay the redo journal: slots 0..jpos-1 (move_one is final already: it is set by move 0 and a swap
-    //      is move 1).  Work of one record, split over the pair as in step_pair_kernel: lower lane the peg,
-    //      links 0, 1 (west end = the cell) and 4, 5 (west end = the target), the single-cell fill's START;
-    //      upper lane START / END gained, links 2, 3 and 6, 7, the fill's END; conditions are sign-extended
-    //      record bits ANDed into the values ----
     uint32_t *const wq = lds + D_REG + bl * (LFB / 4);  // word w of this board's links + flags: wq + 6 w
-#pragma unroll
-    for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-      if (s < jpos) {  // wave-uniform
-        const uint32_t e = jr[s];
-        const int cell = (int)(e & 1023u);
-        const uint32_t valid = (uint32_t)((int32_t)e >> 31);
-        const uint32_t bit = (1u << (cell & 31)) & valid;  // empty record: every OR is a no-op
-        const uint32_t eo = e >> own_sh;  // bits 0, 1: this lane's links at the cell; bits 4, 5: at the targets
-        uint32_t *const g = wq + 6 * (cell >> 5);
-        lds_or2(g + link_lo, bit & (uint32_t)sbit(eo, 0), bit & (uint32_t)sbit(eo, 1));
-        lds_or2(g + 4, bit & hm & (uint32_t)sbit(e, 19), bit & hm & (uint32_t)sbit(e, 20));
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const uint32_t on = (uint32_t)sbit(eo, 4 + j) & valid;
-          const int tc = cell + (int)((uint32_t)(j ? dlt1 : dlt0) & on);
-          lds_or(wq + 6 * (tc >> 5) + link_lo + j, (1u << (tc & 31)) & on);
-        }
-        if (__ballot((e & (twx::kJFillStart | twx::kJFillEnd)) != 0u)) {
-          // the single neighbour a fill flagged: lower lane START, upper lane END
-          const int fd = (int)((e >> twx::kJFillDirShift) & 7u);
-          const int t = cell + ((int)((twx::kDxPack >> (4 * fd)) & 15u) - 2) * N + (int)((twx::kDyPack >> (4 * fd)) & 15u) - 2;
-          const uint32_t on = (uint32_t)sbit(e >> 27, h) & valid;
-          const int tt = on ? t : cell;  // (no fill: t is meaningless and may lie outside the board)
-          lds_or(wq + 6 * (tt >> 5) + (up ? 5 : 4), (1u << (tt & 31)) & on);
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < twx::kJournalSlots - 1; s++) {
-      if (s < jpos) {  // wave-uniform
-        const uint32_t e = jr[s];
-        const int cell = (int)(e & 1023u);
-        const uint32_t bit = (1u << (cell & 31)) & (uint32_t)((int32_t)e >> 31);
-        if (__ballot((e & twx::kJSwap) != 0u))  // rare: undo red's first peg on a swap (tb.cc:450-455)
-          lds_and(pegw((int)(move_one >> 5)), (e & twx::kJSwap) ? ~(1u << (move_one & 31)) : 0xffffffffu);
-        if (!up) lds_or(pegw(cell >> 5) + ((e >> 10) & 1u), bit);
-      }
-    }
-    wave_sync();
 
     const int player = (int)(counter & 1u);
     const bool open = (result == 0u);
@@ -625,7 +567,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     int32_t *__restrict__ actions_out, uint8_t *__restrict__ status, uint32_t seed, uint32_t first_id, int flags,
     int jpos, uint32_t *__restrict__ ticket, TicketBases tbase, int nstatic) {
   (void)jpos;
-  step_window_full_body<N>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, 0, ticket, tbase, nstatic);
+  step_window_full_body<N>(state, bpad, batch, actions, actions_out, status, seed, first_id, flags, ticket, tbase, nstatic);
 }
 
 #endif  // TWIXT_WINDOW_KERNEL_H_
