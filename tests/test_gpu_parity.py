@@ -595,15 +595,16 @@ def test_argument_errors_with_a_handle(torch_mod):
     other.close()
 
 
-def test_hipgraph_replay(torch_mod, monkeypatch):
+@pytest.mark.parametrize("n,batch", [(8, 4096), (24, 3000)])
+def test_hipgraph_replay(torch_mod, monkeypatch, n, batch):
     """TWX_GRAPH_SAFE=1 switches the host-side launch counters off (journal period 1, static
     batch order, no alternating order): every launch of twx_step_random then has constant
     arguments and a captured hipGraph of steps may be replayed: 4 steps captured once,
-    replayed 10 times."""
+    replayed 10 times.  (N=24: the split layout's windowed kernel with every launch a compaction.)"""
     import oracle_binding as ob
     torch = torch_mod
     monkeypatch.setenv("TWX_GRAPH_SAFE", "1")
-    n, batch, seed = 8, 4096, 77
+    seed = 77
     env = make_env(n, batch, first=3)
     acts = torch.empty((4, batch), dtype=torch.int32, device="cuda")
     stat = torch.empty((4, batch), dtype=torch.uint8, device="cuda")
