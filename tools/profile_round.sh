@@ -10,6 +10,25 @@ mkdir -p $out
 B="python3 bench.py --no-cpu-baseline --no-rollout --no-observation"
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/stats -- $B --steps 500 --warmup 20 > $out/bench_under_rocprof.json 2> $out/stats.log
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/${tag}_kernel_stats.csv
+# the same trace reduced to the TIMED launches (the stats average also covers the prologue, whose boards are
+# young and fetch fewer windows, and the launches timed one by one afterwards): which launches were timed is in the
+# bench line of the traced run (prologue, warm-up, steps x blocks)
+python3 - "$(find $out/stats -name '*kernel_trace.csv' | head -1)" $out/bench_under_rocprof.json $out/${tag}_kernel_timed.json <<'PY'
+import csv, json, sys
+b = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+first = b["config"]["prologue_steps"] + b["warmup"]
+count = b["steps"] * b["timed_blocks"]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "step_" in r["Kernel_Name"] and "<24>" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+timed = dur[first:first + count]
+json.dump({"launches_in_trace": len(rows), "first_timed_launch": first, "timed_launches": len(timed),
+           "mean_duration_us_timed": sum(timed) / len(timed), "mean_duration_us_all": sum(dur) / len(dur),
+           "hip_event_kernel_ms_of_the_same_run": b["roofline"]["kernel_ms"],
+           "note": "rocprofv3 --kernel-trace of bench.py --steps 500 --warmup 20; the HIP-event figure of the same run "
+                   "also holds the gaps between launches"},
+          open(sys.argv[3], "w"), indent=1)
+PY
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/fetch -- $B --steps 64 --warmup 0 > $out/fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/write -- $B --steps 64 --warmup 0 > $out/write.log 2>&1
 python3 tools/pmc_traffic.py $out/fetch $out/write $out/$tag
